@@ -1,0 +1,376 @@
+"""ctypes binding of the CPU oracle (oracle/liblamp_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the lamp_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblamp_oracle.so")
+
+
+def build(force=False):
+    """Compile the oracle with gcc (a few seconds)."""
+    srcs = ["lo_linalg.c", "lo_kdtree.c", "lo_gicp.c", "lo_icp_loop.c", "lamp_oracle.h"]
+    if not force and os.path.exists(_LIB_PATH):
+        newest = max(os.path.getmtime(os.path.join(_HERE, s)) for s in srcs)
+        if os.path.getmtime(_LIB_PATH) >= newest:
+            return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "liblamp_oracle.so"],
+                          stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class GicpParams(C.Structure):
+    _fields_ = [("corr_dist", C.c_double), ("tf_epsilon", C.c_double),
+                ("rotation_epsilon", C.c_double), ("max_iterations", C.c_int),
+                ("max_inner_iterations", C.c_int), ("k_correspondences", C.c_int),
+                ("gicp_epsilon", C.c_double), ("cov_from_knn", C.c_int), ("solver", C.c_int),
+                ("use_kdtree", C.c_int), ("threads", C.c_int)]
+
+
+class GicpResult(C.Structure):
+    _fields_ = [("final_transformation", C.c_float * 16), ("converged", C.c_int),
+                ("iterations", C.c_int), ("last_num_correspondences", C.c_int),
+                ("failure", C.c_int), ("last_delta", C.c_double)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3)]
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("gicp", GicpParams), ("init_method", C.c_int), ("covariance_method", C.c_int),
+                ("max_tolerable_fitness", C.c_double), ("transform_thresholding", C.c_int),
+                ("max_translation", C.c_double), ("max_rotation_deg", C.c_double),
+                ("rot_sigma", C.c_double), ("trans_sigma", C.c_double),
+                ("use_fixed_covariances", C.c_int)]
+
+
+class Alignment(C.Structure):
+    _fields_ = [("status", C.c_int), ("T_icp", C.c_float * 16), ("delta", Pose),
+                ("fitness", C.c_double), ("covariance", C.c_double * 36), ("iterations", C.c_int),
+                ("converged", C.c_int)]
+
+
+SOLVER_BFGS, SOLVER_GN = 0, 1
+INIT_IDENTITY, INIT_ODOMETRY, INIT_ODOM_ROTATION, INIT_FEATURES, INIT_TEASERPP, INIT_CANDIDATE = range(6)
+COV_POINT2POINT, COV_POINT2PLANE = 0, 1
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.lo_fitness_score.restype = C.c_double
+        _lib.lo_mat6_det.restype = C.c_double
+        _lib.lo_kdtree_build.restype = C.c_void_p
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def base_gicp_params(**kw):
+    """icp_lc block of the reference's base-station config
+    (loop_closure/config/laser_parameters.yaml:224-243) + SetupICP (IcpLoopComputation.cc:194-203)."""
+    p = GicpParams()
+    lib().lo_gicp_default_params(C.byref(p))
+    p.corr_dist = 0.5
+    p.tf_epsilon = 1e-10
+    p.max_iterations = 200
+    p.max_inner_iterations = 50
+    p.threads = 1
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def transform_points_f32(T, xyz):
+    T = _f32(T).reshape(16)
+    xyz = _f32(xyz)
+    out = np.empty_like(xyz)
+    lib().lo_transform_points_f32(_p(T, C.c_float), _p(xyz, C.c_float), len(xyz), _p(out, C.c_float))
+    return out
+
+
+def transform_points_f64(T, xyz):
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    xyz = _f32(xyz)
+    out = np.empty_like(xyz)
+    lib().lo_transform_points_f64(_p(T, C.c_double), _p(xyz, C.c_float), len(xyz), _p(out, C.c_float))
+    return out
+
+
+def mat4f_mul(a, b):
+    a = _f32(a).reshape(16)
+    b = _f32(b).reshape(16)
+    out = np.empty(16, np.float32)
+    lib().lo_mat4f_mul(_p(a, C.c_float), _p(b, C.c_float), _p(out, C.c_float))
+    return out.reshape(4, 4)
+
+
+def nn_brute(q, t):
+    q, t = _f32(q), _f32(t)
+    idx = np.empty(len(q), np.int32)
+    d2 = np.empty(len(q), np.float32)
+    lib().lo_nn_brute(_p(q, C.c_float), len(q), _p(t, C.c_float), len(t), _p(idx, C.c_int32),
+                      _p(d2, C.c_float))
+    return idx, d2
+
+
+def knn_brute(q, t, k):
+    q, t = _f32(q), _f32(t)
+    idx = np.empty((len(q), k), np.int32)
+    d2 = np.empty((len(q), k), np.float32)
+    lib().lo_knn_brute(_p(q, C.c_float), len(q), _p(t, C.c_float), len(t), k, _p(idx, C.c_int32),
+                       _p(d2, C.c_float))
+    return idx, d2
+
+
+def kdtree_knn(q, t, k=1, threads=1):
+    q, t = _f32(q), _f32(t)
+    idx = np.empty((len(q), k), np.int32)
+    d2 = np.empty((len(q), k), np.float32)
+    L = lib()
+    tree = C.c_void_p(L.lo_kdtree_build(_p(t, C.c_float), len(t)))
+    L.lo_kdtree_knn(tree, _p(q, C.c_float), len(q), k, _p(idx, C.c_int32), _p(d2, C.c_float), threads)
+    L.lo_kdtree_free(tree)
+    return idx, d2
+
+
+def cov_from_normals(normals):
+    normals = _f32(normals)
+    out = np.empty((len(normals), 3, 3), np.float64)
+    lib().lo_cov_from_normals(_p(normals, C.c_float), len(normals), _p(out, C.c_double))
+    return out
+
+
+def cov_knn(xyz, k=20, eps=1e-3, threads=1):
+    xyz = _f32(xyz)
+    out = np.empty((len(xyz), 3, 3), np.float64)
+    rc = lib().lo_cov_knn(_p(xyz, C.c_float), len(xyz), k, C.c_double(eps), _p(out, C.c_double), threads)
+    return out if rc == 0 else None
+
+
+def gicp_align(params, src_xyz, src_normals, tgt_xyz, tgt_normals, guess=None, trace_cap=0):
+    src_xyz, src_normals = _f32(src_xyz), _f32(src_normals)
+    tgt_xyz, tgt_normals = _f32(tgt_xyz), _f32(tgt_normals)
+    guess = _f32(np.eye(4) if guess is None else guess).reshape(16)
+    res = GicpResult()
+    tr_idx = tr_T = None
+    pi = pT = None
+    if trace_cap > 0:
+        tr_idx = np.full((trace_cap, len(src_xyz)), -2, np.int32)
+        tr_T = np.zeros((trace_cap, 16), np.float32)
+        pi, pT = _p(tr_idx, C.c_int32), _p(tr_T, C.c_float)
+    lib().lo_gicp_align(C.byref(params), _p(src_xyz, C.c_float), _p(src_normals, C.c_float),
+                        len(src_xyz), _p(tgt_xyz, C.c_float), _p(tgt_normals, C.c_float),
+                        len(tgt_xyz), _p(guess, C.c_float), C.byref(res), pi, pT, trace_cap)
+    out = {
+        "T": np.array(res.final_transformation, np.float32).reshape(4, 4),
+        "converged": bool(res.converged),
+        "iterations": res.iterations,
+        "m": res.last_num_correspondences,
+        "failure": res.failure,
+        "delta": res.last_delta,
+    }
+    if trace_cap > 0:
+        out["trace_idx"] = tr_idx
+        out["trace_T"] = tr_T.reshape(trace_cap, 4, 4)
+    return out
+
+
+def gicp_cost_grad(src_guess, tgt, src_idx, tgt_idx, mahal, x):
+    src_guess, tgt = _f32(src_guess), _f32(tgt)
+    si = np.ascontiguousarray(src_idx, np.int32)
+    ti = np.ascontiguousarray(tgt_idx, np.int32)
+    mahal = np.ascontiguousarray(mahal, np.float64)
+    x = np.ascontiguousarray(x, np.float64)
+    f = C.c_double()
+    g = np.empty(6, np.float64)
+    lib().lo_gicp_cost_grad(_p(src_guess, C.c_float), _p(tgt, C.c_float), _p(si, C.c_int32),
+                            _p(ti, C.c_int32), len(si), _p(mahal, C.c_double), _p(x, C.c_double),
+                            C.byref(f), _p(g, C.c_double))
+    return f.value, g
+
+
+def apply_state(x):
+    x = np.ascontiguousarray(x, np.float64)
+    T = np.empty(16, np.float32)
+    lib().lo_apply_state(_p(x, C.c_double), _p(T, C.c_float))
+    return T.reshape(4, 4)
+
+
+def fitness_score(src, tgt, T, use_kdtree=True, threads=1):
+    src, tgt = _f32(src), _f32(tgt)
+    T = _f32(T).reshape(16)
+    idx = np.empty(len(src), np.int32)
+    f = lib().lo_fitness_score(_p(src, C.c_float), len(src), _p(tgt, C.c_float), len(tgt),
+                               _p(T, C.c_float), _p(idx, C.c_int32), int(use_kdtree), threads)
+    return f, idx
+
+
+def normalize_cloud(xyz):
+    xyz = _f32(xyz)
+    out = np.empty_like(xyz)
+    lib().lo_normalize_cloud(_p(xyz, C.c_float), len(xyz), _p(out, C.c_float))
+    return out
+
+
+def compute_ap(query_normalized, ref_normals, corr, T):
+    qn, rn = _f32(query_normalized), _f32(ref_normals)
+    corr = np.ascontiguousarray(corr, np.int64)
+    T = _f32(T).reshape(16)
+    Ap = np.empty(36, np.float64)
+    lib().lo_compute_ap(_p(qn, C.c_float), len(qn), _p(rn, C.c_float), len(rn), _p(corr, C.c_int64),
+                        len(corr), _p(T, C.c_float), _p(Ap, C.c_double))
+    return Ap.reshape(6, 6)
+
+
+def icp_observability(xyz, normals):
+    xyz, normals = _f32(xyz), _f32(normals)
+    e = np.empty(3, np.float64)
+    lib().lo_icp_observability(_p(xyz, C.c_float), _p(normals, C.c_float), len(xyz), _p(e, C.c_double))
+    return e
+
+
+def icp_cov_point_plane(scan1_xyz, scan2_normals, corr, T, rot_sigma=0.01, trans_sigma=0.01):
+    s1, n2 = _f32(scan1_xyz), _f32(scan2_normals)
+    corr = np.ascontiguousarray(corr, np.int64)
+    T = _f32(T).reshape(16)
+    cov = np.empty(36, np.float64)
+    Ap = np.empty(36, np.float64)
+    lib().lo_icp_cov_point_plane(_p(s1, C.c_float), len(s1), _p(n2, C.c_float), len(n2),
+                                 _p(corr, C.c_int64), len(corr), _p(T, C.c_float),
+                                 C.c_double(rot_sigma), C.c_double(trans_sigma), _p(cov, C.c_double),
+                                 _p(Ap, C.c_double))
+    return cov.reshape(6, 6), Ap.reshape(6, 6)
+
+
+def icp_cov_point_point(aligned_xyz, T, fitness):
+    a = _f32(aligned_xyz)
+    T = _f32(T).reshape(16)
+    cov = np.empty(36, np.float64)
+    lib().lo_icp_cov_point_point(_p(a, C.c_float), len(a), _p(T, C.c_float), C.c_double(fitness),
+                                 _p(cov, C.c_double))
+    return cov.reshape(6, 6)
+
+
+def pose_from_quat(q_wxyz, t):
+    q = np.ascontiguousarray(q_wxyz, np.float64)
+    t = np.ascontiguousarray(t, np.float64)
+    p = Pose()
+    lib().lo_pose_from_quat(_p(q, C.c_double), _p(t, C.c_double), C.byref(p))
+    return p
+
+
+def pose_between(a, b):
+    out = Pose()
+    lib().lo_pose_between(C.byref(a), C.byref(b), C.byref(out))
+    return out
+
+
+def pose_inverse(a):
+    out = Pose()
+    lib().lo_pose_inverse(C.byref(a), C.byref(out))
+    return out
+
+
+def pose_logmap(a):
+    xi = np.empty(6, np.float64)
+    lib().lo_pose_logmap(C.byref(a), _p(xi, C.c_double))
+    return xi
+
+
+def pose_to_np(p):
+    return np.array(p.R, np.float64).reshape(3, 3), np.array(p.t, np.float64)
+
+
+def base_icp_params(**kw):
+    """Reference base-station block (laser_parameters.yaml:205-243,
+    lamp/config/precision_parameters.yaml:10-11)."""
+    p = IcpParams()
+    p.gicp = base_gicp_params()
+    p.init_method = INIT_ODOMETRY
+    p.covariance_method = COV_POINT2PLANE
+    p.max_tolerable_fitness = 0.9
+    p.transform_thresholding = 1
+    p.max_translation = 20.0
+    p.max_rotation_deg = 50.0
+    p.rot_sigma = 0.01
+    p.trans_sigma = 0.01
+    p.use_fixed_covariances = 0
+    for k, v in kw.items():
+        if hasattr(p.gicp, k) and not hasattr(p, k):
+            setattr(p.gicp, k, v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def perform_alignment(params, src_xyz, src_normals, tgt_xyz, tgt_normals, scan1_xyz,
+                      scan2_normals, pose_21_odom, pose_21_cand=None):
+    a = [_f32(v) for v in (src_xyz, src_normals, tgt_xyz, tgt_normals, scan1_xyz, scan2_normals)]
+    out = Alignment()
+    if pose_21_cand is None:
+        pose_21_cand = pose_21_odom
+    lib().lo_perform_alignment(C.byref(params), _p(a[0], C.c_float), _p(a[1], C.c_float), len(a[0]),
+                               _p(a[2], C.c_float), _p(a[3], C.c_float), len(a[2]),
+                               _p(a[4], C.c_float), len(a[4]), _p(a[5], C.c_float), len(a[5]),
+                               C.byref(pose_21_odom), C.byref(pose_21_cand), C.byref(out))
+    R, t = pose_to_np(out.delta)
+    return {
+        "status": out.status,
+        "T_icp": np.array(out.T_icp, np.float32).reshape(4, 4),
+        "delta_R": R,
+        "delta_t": t,
+        "fitness": out.fitness,
+        "covariance": np.array(out.covariance, np.float64).reshape(6, 6),
+        "iterations": out.iterations,
+        "converged": bool(out.converged),
+    }
+
+
+def mat3_inverse(a):
+    a = np.ascontiguousarray(a, np.float64).reshape(9)
+    out = np.empty(9, np.float64)
+    lib().lo_mat3_inverse(_p(a, C.c_double), _p(out, C.c_double))
+    return out.reshape(3, 3)
+
+
+def mat6_inverse(a):
+    a = np.ascontiguousarray(a, np.float64).reshape(36)
+    out = np.empty(36, np.float64)
+    lib().lo_mat6_inverse(_p(a, C.c_double), _p(out, C.c_double))
+    return out.reshape(6, 6)
+
+
+def sym_eig(a):
+    a = np.ascontiguousarray(a, np.float64)
+    n = a.shape[0]
+    ev = np.empty(n, np.float64)
+    V = np.empty(n * n, np.float64)
+    lib().lo_sym_eig(_p(a.reshape(-1), C.c_double), n, _p(ev, C.c_double), _p(V, C.c_double))
+    return ev, V.reshape(n, n)
+
+
+def ldlt(a):
+    a = np.ascontiguousarray(a, np.float64).reshape(36)
+    L = np.empty(36, np.float64)
+    D = np.empty(6, np.float64)
+    tr = np.empty(6, np.int32)
+    lib().lo_ldlt(_p(a, C.c_double), _p(L, C.c_double), _p(D, C.c_double), _p(tr, C.c_int))
+    return L.reshape(6, 6), D, tr
