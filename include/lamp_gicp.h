@@ -1,0 +1,204 @@
+/*
+ * lamp_gicp.h — C ABI of the MI355X loop-closure verification engine.
+ *
+ * Drop-in boundary for LAMP's loop_closure stage 4.  The reference has no FFI for this
+ * path: the stage is the C++ class lamp_loop_closure::IcpLoopComputation
+ * (loop_closure/include/loop_closure/IcpLoopComputation.h:24-159) behind the abstract
+ * lamp_loop_closure::LoopComputation (include/loop_closure/LoopComputation.h:22-68).  The
+ * entry points below are what a sibling subclass binds instead of calling PCL: each comment
+ * names the reference member it replaces.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Matrices are ROW-MAJOR.
+ * Every function returns 0 (or a non-negative count) on success and a negative
+ * LGICP_E_* code on a call-level error; lgicp_last_error() gives the text.  Per-pair
+ * failures are NOT errors: they come back as lgicp_result.status, one value per reject
+ * reason of IcpLoopComputation::PerformAlignment, so the adapter emits the same edge set.
+ *
+ * Threading: one context = one submitting thread (the reference's single ROS spinner
+ * thread, IcpLoopComputation.cc:189-190); add_keyframe/add_pose must not overlap submit.
+ */
+#ifndef LAMP_GICP_H_
+#define LAMP_GICP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGICP_ABI_VERSION 1
+
+/* call-level error codes */
+enum {
+  LGICP_OK = 0,
+  LGICP_E_INVALID = -1,     /* bad argument */
+  LGICP_E_HIP = -2,         /* HIP runtime error (text in lgicp_last_error) */
+  LGICP_E_NO_DEVICE = -3,   /* no usable gfx950 device */
+  LGICP_E_UNSUPPORTED = -4, /* configuration not implemented on the device path */
+  LGICP_E_NOMEM = -5
+};
+
+/* IcpLoopComputation::IcpInitMethod (IcpLoopComputation.h:135-142) */
+enum {
+  LGICP_INIT_IDENTITY = 0,
+  LGICP_INIT_ODOMETRY = 1,
+  LGICP_INIT_ODOM_ROTATION = 2,
+  LGICP_INIT_FEATURES = 3,
+  LGICP_INIT_TEASERPP = 4,
+  LGICP_INIT_CANDIDATE = 5
+};
+/* IcpLoopComputation::IcpCovarianceMethod (IcpLoopComputation.h:144) */
+enum { LGICP_COV_POINT2POINT = 0, LGICP_COV_POINT2PLANE = 1 };
+
+/* per-pair outcome: one value per `return false` of PerformAlignment */
+enum {
+  LGICP_PAIR_OK = 0,
+  LGICP_PAIR_MISSING_SCAN = 1,   /* IcpLoopComputation.cc:438-442 */
+  LGICP_PAIR_MISSING_POSE = 2,   /* :444-448 */
+  LGICP_PAIR_EMPTY_CLOUD = 3,    /* :458-465 */
+  LGICP_PAIR_INIT_REJECTED = 4,  /* :523-526 (SAC score too high) */
+  LGICP_PAIR_NONFINITE = 5,      /* :558-559 */
+  LGICP_PAIR_NOT_CONVERGED = 6,  /* :580-584 */
+  LGICP_PAIR_FITNESS = 7,        /* :588-593 */
+  LGICP_PAIR_TRANSFORM = 8       /* :604-614 */
+};
+
+/* Every tunable of the path.  Field comments give the reference parameter
+ * (loop_closure/config/laser_parameters.yaml, IcpLoopComputation::LoadParameters
+ * IcpLoopComputation.cc:58-167) or the hard-coded value it mirrors. */
+typedef struct lgicp_config {
+  int abi_version;            /* LGICP_ABI_VERSION */
+  int device;                 /* HIP device ordinal */
+  /* icp_lc/... and SetupICP (IcpLoopComputation.cc:194-203) */
+  double tf_epsilon;          /* icp_lc/tf_epsilon */
+  double corr_dist;           /* icp_lc/corr_dist */
+  int iterations;             /* icp_lc/iterations */
+  int optimizer_iterations;   /* setMaximumOptimizerIterations(50) */
+  double rotation_epsilon;    /* gicp.h:128 (2e-3) */
+  int k_correspondences;      /* gicp.h:121 (20) */
+  double gicp_epsilon;        /* gicp.h:127 (1e-3) */
+  int covariance_from_knn;    /* 0: covariances from stored normals (the path the reference
+                                 takes, gicp.hpp:81-82); 1: k-NN + SVD branch (gicp.hpp:83-155) */
+  int init_method;            /* icp_initialization_method */
+  int covariance_method;      /* icp_covariance_calculation */
+  double max_tolerable_fitness;
+  int transform_thresholding; /* icp_lc/transform_thresholding */
+  double max_translation;     /* icp_lc/max_translation */
+  double max_rotation_deg;    /* icp_lc/max_rotation */
+  int num_prev_scans;         /* sac_ia/num_prev_scans */
+  int num_next_scans;         /* sac_ia/num_next_scans */
+  int accumulate_source;      /* sac_ia/b_accumulate_source */
+  double laser_lc_rot_sigma;  /* precision_parameters.yaml:10 */
+  double laser_lc_trans_sigma;/* precision_parameters.yaml:11 */
+  int use_fixed_covariances;  /* b_use_fixed_covariances */
+  /* feature front end (SAC-IA / TEASER++), IcpLoopComputation.cc:90-135 */
+  int sac_iterations;
+  double sac_features_radius;
+  double sac_fitness_score_threshold;
+  double harris_threshold;
+  int harris_suppression;
+  double harris_radius;
+  int harris_refine;
+  int harris_response;
+  /* device-side knobs with no counterpart in the reference */
+  size_t workspace_bytes;     /* upper bound for per-batch device scratch (0 = 16 GiB) */
+  int reserved[8];
+} lgicp_config;
+
+/* pose_graph_msgs/LoopCandidate (pose_graph_msgs/msg/LoopCandidate.msg:1-18) */
+typedef struct lgicp_candidate {
+  uint64_t key_from;          /* source keyframe, key1 of PerformAlignment */
+  uint64_t key_to;            /* target keyframe, key2 */
+  double pose_from_q[4];      /* orientation w,x,y,z */
+  double pose_from_t[3];
+  double pose_to_q[4];
+  double pose_to_t[3];
+} lgicp_candidate;
+
+/* what PerformAlignment returns + what CreateLoopClosureEdge (LoopComputation.cc:67-87)
+ * needs to fill a pose_graph_msgs/PoseGraphEdge */
+typedef struct lgicp_result {
+  uint64_t key_from, key_to;
+  int32_t status;             /* LGICP_PAIR_* */
+  int32_t iterations;         /* nr_iterations_ of the GICP outer loop */
+  int32_t converged;          /* hasConverged() */
+  int32_t n_correspondences;  /* inliers of the last outer iteration */
+  float T_icp[16];            /* getFinalTransformation(): source -> target, before PoseInverse */
+  double delta_R[9];          /* after gu::PoseInverse (IcpLoopComputation.cc:617): edge rotation */
+  double delta_t[3];          /* edge translation */
+  double delta_q[4];          /* same rotation as a quaternion w,x,y,z (edge.pose.orientation) */
+  double fitness;             /* getFitnessScore() -> edge.range_error (IcpLoopComputation.cc:298) */
+  double covariance[36];      /* edge.covariance, order rotX,rotY,rotZ,x,y,z */
+  double information[36];     /* Ap of ComputeAp_ForPoint2PlaneICP / 0.05^2 (POINT2PLANE) or
+                                 inverse of covariance otherwise; zero when not computed */
+} lgicp_result;
+
+typedef struct lgicp_stats {
+  uint64_t pairs_submitted, pairs_ok;
+  uint64_t outer_iterations;    /* summed over pairs */
+  uint64_t nn_launches;         /* launches of the 1-NN kernel */
+  double nn_distance_evals;     /* N*M summed over launches and pairs (8 flop each) */
+  double nn_ms, reduce_ms, solve_ms, cov_ms, post_ms, total_ms; /* hipEvent time, last submit */
+  double last_nn_kernel_ms;     /* average duration of one 1-NN launch in the last submit */
+  double last_nn_evals_per_launch;
+} lgicp_stats;
+
+typedef struct lgicp_ctx lgicp_ctx;
+
+/* values of the reference's "base" (base_station != 0) or "robot" parameter block */
+void lgicp_default_config(lgicp_config* cfg, int base_station);
+
+/* IcpLoopComputation::Initialize / LoadParameters / SetupICP */
+int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out);
+void lgicp_destroy(lgicp_ctx* ctx);
+const char* lgicp_last_error(const lgicp_ctx* ctx); /* ctx may be NULL: last create error */
+
+/* IcpLoopComputation::KeyedScanCallback (IcpLoopComputation.cc:377-392): first insert of a
+ * key wins.  xyz / normals point at the first float of point 0; stride_bytes is the distance
+ * between points (48 for pcl::PointXYZINormal, with normals = xyz + 4 floats).  normals may
+ * be NULL (all-zero normals).  Returns 1 if stored, 0 if the key already had a scan. */
+int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const float* normals,
+                       size_t n_points, size_t stride_bytes);
+/* IcpLoopComputation::KeyedPoseCallback (IcpLoopComputation.cc:394-418): first wins. */
+int lgicp_add_pose(lgicp_ctx* ctx, uint64_t key, const double q_wxyz[4], const double t[3]);
+int lgicp_has_keyframe(const lgicp_ctx* ctx, uint64_t key);
+int lgicp_has_pose(const lgicp_ctx* ctx, uint64_t key);
+
+/* The batch body of IcpLoopComputation::ComputeTransforms (IcpLoopComputation.cc:243-367):
+ * PerformAlignment for every candidate, all pairs in flight on the device at once (what the
+ * reference's ThreadPool, ThreadPool.h:17-115, does with host threads).  out[n] is caller
+ * allocated; out[i] belongs to cand[i].  Blocking, like the reference's future.wait() loop. */
+int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n, lgicp_result* out);
+
+int lgicp_get_stats(const lgicp_ctx* ctx, lgicp_stats* out);
+
+/* ------------------------------------------------------------------ kernel-level entry
+ * points (host buffers in, host buffers out; used by the parity tests and by callers that
+ * want one stage only).  Points are packed xyz floats (stride 3). */
+
+/* one pass of the correspondence search of gicp.hpp:463-498: q = T * src (float), 1-NN in
+ * tgt, squared distance; idx = -1 where no neighbour exists.  n_splits > 1 forces the
+ * target to be split over that many workgroups per query tile (0 = automatic). */
+int lgicp_nn_search(lgicp_ctx* ctx, const float T[16], const float* src_xyz, size_t n_src,
+                    const float* tgt_xyz, size_t n_tgt, int32_t* idx, float* d2, int n_splits);
+/* CalculateCovarianceFromNormals (gicp_utils.h:50-62): cov9 is [n][9] doubles */
+int lgicp_covariances_from_normals(lgicp_ctx* ctx, const float* normals, size_t n, double* cov9);
+/* computeCovariances k-NN branch (gicp.hpp:83-155) */
+int lgicp_covariances_knn(lgicp_ctx* ctx, const float* xyz, size_t n, int k, double eps,
+                          double* cov9);
+/* MultithreadedGICP align (gicp.hpp:405-617) for one pair with an explicit guess */
+int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* src_normals, size_t n_src,
+                const float* tgt_xyz, const float* tgt_normals, size_t n_tgt,
+                const float guess[16], float final_T[16], int* converged, int* iterations,
+                double* fitness);
+/* NormalizePCloud + ComputeAp_ForPoint2PlaneICP (PointCloudUtils.cc:39-59,115-163):
+ * corr[i] >= n_ref contributes a zero normal.  Ap is 6x6 row-major. */
+int lgicp_compute_ap(lgicp_ctx* ctx, const float* query_xyz, size_t n_query,
+                     const float* ref_normals, size_t n_ref, const int32_t* corr, size_t n_corr,
+                     const float T[16], int normalize_query, double Ap[36]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAMP_GICP_H_ */

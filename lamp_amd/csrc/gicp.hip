@@ -1,0 +1,547 @@
+// gicp.hip — Mahalanobis linearisation/reduction, on-device Gauss-Newton solve and SE(3)
+// update, and the post-alignment reductions (fitness, Ap) for gfx950.
+//
+// Reference being replaced: the serial O(m) cost/gradient loops the BFGS optimiser calls
+// (lamp_utils/include/lamp_utils/gicp.hpp:290-402), the Mahalanobis build inside the lookup
+// loop (gicp.hpp:483-497), estimateRigidTransformationBFGS (gicp.hpp:217-287), the
+// convergence test (gicp.hpp:526-541,564-580), pcl getFitnessScore and
+// ComputeAp_ForPoint2PlaneICP (lamp_utils/src/PointCloudUtils.cc:115-163).
+//
+// The residual res = Theta*(p,1) - q is linear in the 12 entries of Theta = [R|t], so the
+// objective (1/m) sum res^T M res of one outer iteration is a quadratic form in
+// delta = vec(Theta - Theta0).  One HBM-bound pass over the correspondences reduces it to
+// 74 doubles per pair (wave shuffles, then LDS across the 4 waves, then a per-chunk slab);
+// the Gauss-Newton iterations on the 6 Euler parameters then cost O(1) each and run in the
+// solve kernel, which also applies the reference's convergence test and produces the next
+// float transformation with the reference's applyState arithmetic (gicp.hpp:619-634).
+#include "lgicp_device.h"
+
+namespace lgicp {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// second-moment slot of (k,l), k <= l, in the order xx xy xz x1 yy yz y1 zz z1 11
+__host__ __device__ constexpr int uu_slot(int k, int l) {
+  return k == 0 ? l : (k == 1 ? 3 + l : (k == 2 ? 5 + l : 9));
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
+    const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
+    const PairState* __restrict__ st, const int4* __restrict__ bmap, double corr_dist2,
+    double* __restrict__ partials) {
+  __shared__ double sh[RED_THREADS / 64][NSTAT];
+  const int4 bm = bmap[blockIdx.x];
+  const int pair = bm.x;
+  const PairState& S = st[pair];
+  if (!S.active) return;
+  const PairDev& P = pairs[pair];
+  const CloudDev& SC = clouds[P.src_cloud];
+  const CloudDev& TC = clouds[P.tgt_cloud];
+
+  // R = rotation of transformation_ * guess in double (gicp.hpp:450-460); Theta0 = T widened
+  double R[9], Th[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += (double)S.T[i * 4 + k] * (double)P.guess[k * 4 + j];
+      R[i * 3 + j] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Th[i] = (double)S.T[i];  // rows 0..2 of the 4x4, row-major
+
+  double acc[NSTAT - 1];
+#pragma unroll
+  for (int i = 0; i < NSTAT - 1; ++i) acc[i] = 0.0;
+  int m = 0;
+
+  const int n = P.n_src;
+  const int per = (n + bm.z - 1) / bm.z;
+  const int i0 = bm.y * per;
+  const int i1 = min(n, i0 + per);
+  for (int i = i0 + threadIdx.x; i < i1; i += RED_THREADS) {
+    const nnkey_t key = P.keys[i];
+    if (key == NNKEY_NONE) continue;
+    const float d2 = __uint_as_float((unsigned)(key >> 32));
+    if (!((double)d2 < corr_dist2)) continue;  // gicp.hpp:483
+    const int j = (int)(key & 0xFFFFFFFFu);
+    const float4 pf = P.out[i];
+    const float4 qf = TC.xyz[j];
+    const double* c1 = SC.cov + 6 * (size_t)i;
+    const double* c2 = TC.cov + 6 * (size_t)j;
+    const double a00 = c1[0], a01 = c1[1], a02 = c1[2], a11 = c1[3], a12 = c1[4], a22 = c1[5];
+    // RC = R * C1
+    double RC[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double r0 = R[r * 3], r1 = R[r * 3 + 1], r2 = R[r * 3 + 2];
+      RC[r * 3 + 0] = r0 * a00 + r1 * a01 + r2 * a02;
+      RC[r * 3 + 1] = r0 * a01 + r1 * a11 + r2 * a12;
+      RC[r * 3 + 2] = r0 * a02 + r1 * a12 + r2 * a22;
+    }
+    // S = RC * R^T + C2 (symmetric)
+    double s00 = RC[0] * R[0] + RC[1] * R[1] + RC[2] * R[2] + c2[0];
+    double s01 = RC[0] * R[3] + RC[1] * R[4] + RC[2] * R[5] + c2[1];
+    double s02 = RC[0] * R[6] + RC[1] * R[7] + RC[2] * R[8] + c2[2];
+    double s11 = RC[3] * R[3] + RC[4] * R[4] + RC[5] * R[5] + c2[3];
+    double s12 = RC[3] * R[6] + RC[4] * R[7] + RC[5] * R[8] + c2[4];
+    double s22 = RC[6] * R[6] + RC[7] * R[7] + RC[8] * R[8] + c2[5];
+    // M = S^-1 by cofactors (Eigen's 3x3 inverse, gicp.hpp:493)
+    const double k00 = s11 * s22 - s12 * s12;
+    const double k01 = s02 * s12 - s01 * s22;
+    const double k02 = s01 * s12 - s02 * s11;
+    const double det = s00 * k00 + s01 * k01 + s02 * k02;
+    const double inv = 1.0 / det;
+    double M[6];
+    M[0] = k00 * inv;
+    M[1] = k01 * inv;
+    M[2] = k02 * inv;
+    M[3] = (s00 * s22 - s02 * s02) * inv;
+    M[4] = (s01 * s02 - s00 * s12) * inv;
+    M[5] = (s00 * s11 - s01 * s01) * inv;
+
+    const double u[4] = {(double)pf.x, (double)pf.y, (double)pf.z, 1.0};
+    const double r0 = (Th[0] * u[0] + Th[1] * u[1] + Th[2] * u[2] + Th[3]) - (double)qf.x;
+    const double r1 = (Th[4] * u[0] + Th[5] * u[1] + Th[6] * u[2] + Th[7]) - (double)qf.y;
+    const double r2 = (Th[8] * u[0] + Th[9] * u[1] + Th[10] * u[2] + Th[11]) - (double)qf.z;
+    const double Mr[3] = {M[0] * r0 + M[1] * r1 + M[2] * r2, M[1] * r0 + M[3] * r1 + M[4] * r2,
+                          M[2] * r0 + M[4] * r1 + M[5] * r2};
+    acc[72] += r0 * Mr[0] + r1 * Mr[1] + r2 * Mr[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) acc[60 + k * 3 + a] += u[k] * Mr[a];
+#pragma unroll
+      for (int l = k; l < 4; ++l) {
+        const double ukl = u[k] * u[l];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) acc[uu_slot(k, l) * 6 + e] += ukl * M[e];
+      }
+    }
+    ++m;
+  }
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NSTAT - 1; ++i) {
+    const double v = wave_sum(acc[i]);
+    if (lane == 0) sh[wave][i] = v;
+  }
+  {
+    const double v = wave_sum((double)m);
+    if (lane == 0) sh[wave][NSTAT - 1] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NSTAT) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < RED_THREADS / 64; ++w) s += sh[w][threadIdx.x];
+    partials[((size_t)pair * RED_MAX_CHUNKS + bm.y) * NSTAT + threadIdx.x] = s;
+  }
+}
+
+hipError_t launch_gicp_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
+                              const int4* bmap, int n_blocks, double corr_dist2, double* partials,
+                              hipStream_t stream) {
+  if (n_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gicp_reduce_kernel, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
+                     pairs, st, bmap, corr_dist2, partials);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gauss-Newton on the quadratic form.  Theta index: 3*k + a, k = column (0..3), a = row.
+
+struct QuadForm {
+  double Q[78];  // symmetric 12x12, packed upper triangle (i <= j): i*12 - i*(i-1)/2 + (j-i)
+  double b[12];
+  double c;
+  double Theta0[12];
+};
+
+__device__ __forceinline__ int sym12(int i, int j) {
+  if (i > j) {
+    const int t = i;
+    i = j;
+    j = t;
+  }
+  return i * 12 - (i * (i - 1)) / 2 + (j - i);
+}
+
+__device__ void theta_of_x(const double x[6], double Th[12], double dTh[3][9], bool want_d) {
+  double sf, cf, st, ct, sp, cp;
+  sincos(x[3], &sf, &cf);
+  sincos(x[4], &st, &ct);
+  sincos(x[5], &sp, &cp);
+  // R = Rz(psi) Ry(theta) Rx(phi), row-major
+  const double R[9] = {cp * ct, cp * st * sf - sp * cf, cp * st * cf + sp * sf,
+                       sp * ct, sp * st * sf + cp * cf, sp * st * cf - cp * sf,
+                       -st,     ct * sf,                ct * cf};
+  for (int k = 0; k < 3; ++k)
+    for (int a = 0; a < 3; ++a) Th[k * 3 + a] = R[a * 3 + k];
+  Th[9] = x[0];
+  Th[10] = x[1];
+  Th[11] = x[2];
+  if (want_d) {
+    const double dphi[9] = {0, cp * st * cf + sp * sf, -cp * st * sf + sp * cf,
+                            0, sp * st * cf - cp * sf, -sp * st * sf - cp * cf,
+                            0, ct * cf,                -ct * sf};
+    const double dth[9] = {-cp * st, cp * ct * sf, cp * ct * cf, -sp * st, sp * ct * sf,
+                           sp * ct * cf, -ct,      -st * sf,     -st * cf};
+    const double dpsi[9] = {-sp * ct, -sp * st * sf - cp * cf, -sp * st * cf + cp * sf,
+                            cp * ct,  cp * st * sf - sp * cf,  cp * st * cf + sp * sf,
+                            0,        0,                       0};
+    for (int k = 0; k < 3; ++k)
+      for (int a = 0; a < 3; ++a) {
+        dTh[0][k * 3 + a] = dphi[a * 3 + k];
+        dTh[1][k * 3 + a] = dth[a * 3 + k];
+        dTh[2][k * 3 + a] = dpsi[a * 3 + k];
+      }
+  }
+}
+
+__device__ double quad_eval(const QuadForm& q, const double Th[12], double* grad12) {
+  double d[12];
+  for (int i = 0; i < 12; ++i) d[i] = Th[i] - q.Theta0[i];
+  double f = q.c;
+  for (int i = 0; i < 12; ++i) {
+    double s = 0;
+    for (int j = 0; j < 12; ++j) s += q.Q[sym12(i, j)] * d[j];
+    f += d[i] * (2.0 * q.b[i] + s);
+    if (grad12) grad12[i] = 2.0 * (q.b[i] + s);
+  }
+  return f;
+}
+
+__device__ bool chol6_solve(const double H[36], const double g[6], double dx[6]) {
+  double L[36];
+  for (int i = 0; i < 36; ++i) L[i] = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = H[i * 6 + j];
+      for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+      if (i == j) {
+        if (!(s > 0)) return false;
+        L[i * 6 + i] = sqrt(s);
+      } else {
+        L[i * 6 + j] = s / L[j * 6 + j];
+      }
+    }
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = g[i];
+    for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
+    y[i] = s / L[i * 6 + i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * dx[k];
+    dx[i] = s / L[i * 6 + i];
+  }
+  return true;
+}
+
+// applyState on the identity (gicp.hpp:619-634): Eigen multiplies the three AngleAxisf as
+// float quaternions and converts the product to a rotation matrix
+__device__ void apply_state(const double x[6], float T[16]) {
+  const float az = (float)x[5], ay = (float)x[4], ax = (float)x[3];
+  const float qz[4] = {cosf(0.5f * az), 0.f, 0.f, sinf(0.5f * az)};
+  const float qy[4] = {cosf(0.5f * ay), 0.f, sinf(0.5f * ay), 0.f};
+  const float qx[4] = {cosf(0.5f * ax), sinf(0.5f * ax), 0.f, 0.f};
+  float a[4], q[4];
+  a[0] = qz[0] * qy[0] - qz[1] * qy[1] - qz[2] * qy[2] - qz[3] * qy[3];
+  a[1] = qz[0] * qy[1] + qz[1] * qy[0] + qz[2] * qy[3] - qz[3] * qy[2];
+  a[2] = qz[0] * qy[2] + qz[2] * qy[0] + qz[3] * qy[1] - qz[1] * qy[3];
+  a[3] = qz[0] * qy[3] + qz[3] * qy[0] + qz[1] * qy[2] - qz[2] * qy[1];
+  q[0] = a[0] * qx[0] - a[1] * qx[1] - a[2] * qx[2] - a[3] * qx[3];
+  q[1] = a[0] * qx[1] + a[1] * qx[0] + a[2] * qx[3] - a[3] * qx[2];
+  q[2] = a[0] * qx[2] + a[2] * qx[0] + a[3] * qx[1] - a[1] * qx[3];
+  q[3] = a[0] * qx[3] + a[3] * qx[0] + a[1] * qx[2] - a[2] * qx[1];
+  const float w = q[0], X = q[1], Y = q[2], Z = q[3];
+  const float tx = 2 * X, ty = 2 * Y, tz = 2 * Z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * X, txy = ty * X, txz = tz * X;
+  const float tyy = ty * Y, tyz = tz * Y, tzz = tz * Z;
+  for (int i = 0; i < 16; ++i) T[i] = 0.f;
+  T[0] = 1 - (tyy + tzz);
+  T[1] = txy - twz;
+  T[2] = txz + twy;
+  T[4] = txy + twz;
+  T[5] = 1 - (txx + tzz);
+  T[6] = tyz - twx;
+  T[8] = txz - twy;
+  T[9] = tyz + twx;
+  T[10] = 1 - (txx + tyy);
+  T[3] = (float)x[0];
+  T[7] = (float)x[1];
+  T[11] = (float)x[2];
+  T[15] = 1.f;
+}
+
+__device__ void mat4f_mul(const float a[16], const float b[16], float out[16]) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float s = a[i * 4 + 0] * b[0 * 4 + j];
+      s = s + a[i * 4 + 1] * b[1 * 4 + j];
+      s = s + a[i * 4 + 2] * b[2 * 4 + j];
+      s = s + a[i * 4 + 3] * b[3 * 4 + j];
+      out[i * 4 + j] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restrict__ pairs,
+                                                        PairState* __restrict__ st,
+                                                        const int* __restrict__ n_chunks,
+                                                        const double* __restrict__ partials,
+                                                        SolveParams sp, int* __restrict__ n_done) {
+  __shared__ double stat[NSTAT + 6];
+  const int pair = blockIdx.x;
+  PairState& S = st[pair];
+  if (!S.active) return;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < NSTAT; i += 64) {
+    double s = 0;
+    const int nc = n_chunks[pair];
+    for (int c = 0; c < nc; ++c) s += partials[((size_t)pair * RED_MAX_CHUNKS + c) * NSTAT + i];
+    stat[i] = s;
+  }
+  __syncthreads();
+  if (lane != 0) return;
+
+  const PairDev& P = pairs[pair];
+  const int m = (int)(stat[NSTAT - 1] + 0.5);
+  S.m = m;
+  float T[16], Tprev[16];
+  for (int i = 0; i < 16; ++i) T[i] = S.T[i];
+  for (int i = 0; i < 16; ++i) Tprev[i] = T[i];  // previous_transformation_ = transformation_
+  bool done = false;
+  if (m < 4) {
+    // NotEnoughPointsException -> break out of the loop, converged_ stays false
+    // (gicp.hpp:225-233, 542-547)
+    S.failed = 1;
+    S.converged = 0;
+    done = true;
+  } else {
+    QuadForm q;
+    // expand the 10 x 6 packed moments to the packed symmetric 12x12
+    for (int k = 0; k < 4; ++k)
+      for (int l = k; l < 4; ++l) {
+        const double* s6 = &stat[uu_slot(k, l) * 6];
+        const double Ms[9] = {s6[0], s6[1], s6[2], s6[1], s6[3], s6[4], s6[2], s6[4], s6[5]};
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) {
+            const int i = k * 3 + a, j = l * 3 + b;
+            if (i <= j) q.Q[sym12(i, j)] = Ms[a * 3 + b];
+          }
+      }
+    for (int i = 0; i < 12; ++i) q.b[i] = stat[60 + i];
+    q.c = stat[72];
+    for (int k = 0; k < 3; ++k)
+      for (int a = 0; a < 3; ++a) q.Theta0[k * 3 + a] = (double)T[a * 4 + k];
+    for (int a = 0; a < 3; ++a) q.Theta0[9 + a] = (double)T[a * 4 + 3];
+
+    double x[6];
+    x[0] = T[3];
+    x[1] = T[7];
+    x[2] = T[11];
+    x[3] = atan2((double)T[9], (double)T[10]);
+    x[4] = asin(-(double)T[8]);
+    x[5] = atan2((double)T[4], (double)T[0]);
+    double Th[12], dTh[3][9], g12[12];
+    theta_of_x(x, Th, dTh, true);
+    double f = quad_eval(q, Th, g12);
+    for (int it = 0; it < sp.max_inner_iterations; ++it) {
+      double J[12][6];
+      for (int e = 0; e < 12; ++e)
+        for (int c = 0; c < 6; ++c) J[e][c] = 0.0;
+      for (int a = 0; a < 3; ++a) J[9 + a][a] = 1.0;
+      for (int c = 0; c < 3; ++c)
+        for (int e = 0; e < 9; ++e) J[e][3 + c] = dTh[c][e];
+      double g[6], H[36], QJ[12][6];
+      for (int c = 0; c < 6; ++c) {
+        double s = 0;
+        for (int e = 0; e < 12; ++e) s += J[e][c] * g12[e];
+        g[c] = -s;
+      }
+      for (int e = 0; e < 12; ++e)
+        for (int c = 0; c < 6; ++c) {
+          double s = 0;
+          for (int e2 = 0; e2 < 12; ++e2) s += q.Q[sym12(e, e2)] * J[e2][c];
+          QJ[e][c] = s;
+        }
+      for (int c = 0; c < 6; ++c)
+        for (int c2 = 0; c2 < 6; ++c2) {
+          double s = 0;
+          for (int e = 0; e < 12; ++e) s += J[e][c] * QJ[e][c2];
+          H[c * 6 + c2] = 2.0 * s;
+        }
+      double dx[6];
+      if (!chol6_solve(H, g, dx)) break;
+      double step = 1.0, fn = f, xn[6];
+      bool ok = false;
+      for (int h = 0; h < 30; ++h) {
+        for (int c = 0; c < 6; ++c) xn[c] = x[c] + step * dx[c];
+        theta_of_x(xn, Th, dTh, false);
+        fn = quad_eval(q, Th, nullptr);
+        if (fn < f) {
+          ok = true;
+          break;
+        }
+        step *= 0.5;
+      }
+      if (!ok) break;
+      double mx = 0;
+      for (int c = 0; c < 6; ++c) {
+        mx = fmax(mx, fabs(xn[c] - x[c]));
+        x[c] = xn[c];
+      }
+      theta_of_x(x, Th, dTh, true);
+      f = quad_eval(q, Th, g12);
+      if (mx < 1e-12) break;
+    }
+    apply_state(x, T);
+    // convergence test (gicp.hpp:526-541, 564-580)
+    double delta = 0.;
+    for (int k = 0; k < 4; ++k)
+      for (int l = 0; l < 4; ++l) {
+        const double ratio = (k < 3 && l < 3) ? 1. / sp.rotation_epsilon : 1. / sp.tf_epsilon;
+        const double c_delta = ratio * fabs((double)(Tprev[k * 4 + l] - T[k * 4 + l]));
+        if (c_delta > delta) delta = c_delta;
+      }
+    S.delta = delta;
+    const int it = S.iterations + 1;
+    S.iterations = it;
+    for (int i = 0; i < 16; ++i) S.T[i] = T[i];
+    if (it >= sp.max_iterations || delta < 1) {
+      S.converged = 1;
+      for (int i = 0; i < 16; ++i) Tprev[i] = T[i];
+      done = true;
+    }
+  }
+  for (int i = 0; i < 16; ++i) S.Tprev[i] = Tprev[i];
+  if (done) {
+    float Tf[16], G[16];
+    for (int i = 0; i < 16; ++i) G[i] = P.guess[i];
+    mat4f_mul(Tprev, G, Tf);  // final_transformation_ = previous_ * guess (gicp.hpp:583)
+    for (int i = 0; i < 16; ++i) S.Tfinal[i] = Tf[i];
+    S.active = 0;
+    atomicAdd(n_done, 1);
+  }
+}
+
+hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
+                             const int* n_chunks, const double* partials, SolveParams sp,
+                             int* n_done, hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gicp_solve_kernel, dim3(n_pairs), dim3(64), 0, stream, pairs, st, n_chunks,
+                     partials, sp, n_done);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// After the alignment: fitness = mean squared 1-NN distance of final*source in the target
+// (pcl getFitnessScore), finiteness of the aligned points (IcpLoopComputation.cc:558-559) and
+// Ap = sum H^T H, H = [(a x R n)^T, (R n)^T] (PointCloudUtils.cc:115-163) with a = normalised
+// un-accumulated source point (PointCloudUtils.cc:39-59), n = un-accumulated target normal of
+// its correspondence (zero when the index lies beyond that scan, PointCloudUtils.cc:138-146).
+__global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
+    const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
+    const PairState* __restrict__ st, const int4* __restrict__ bmap,
+    double* __restrict__ partials) {
+  __shared__ double sh[RED_THREADS / 64][NPOST];
+  const int4 bm = bmap[blockIdx.x];
+  const int pair = bm.x;
+  const PairDev& P = pairs[pair];
+  const PairState& S = st[pair];
+  const CloudDev& S1 = clouds[P.scan1_cloud];
+  const CloudDev& S2 = clouds[P.scan2_cloud];
+  const CloudDev& SRC = clouds[P.src_cloud];
+  double R[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) R[a * 3 + b] = (double)S.Tfinal[a * 4 + b];
+  const float tf[12] = {S.Tfinal[0], S.Tfinal[1], S.Tfinal[2],  S.Tfinal[3],
+                        S.Tfinal[4], S.Tfinal[5], S.Tfinal[6],  S.Tfinal[7],
+                        S.Tfinal[8], S.Tfinal[9], S.Tfinal[10], S.Tfinal[11]};
+  const float fac = S1.factor;
+  const float ox = -fac * S1.centroid[0], oy = -fac * S1.centroid[1], oz = -fac * S1.centroid[2];
+
+  double acc[NPOST];
+#pragma unroll
+  for (int i = 0; i < NPOST; ++i) acc[i] = 0.0;
+  const int n = P.n_src;
+  const int per = (n + bm.z - 1) / bm.z;
+  const int i0 = bm.y * per, i1 = min(n, i0 + per);
+  for (int i = i0 + threadIdx.x; i < i1; i += RED_THREADS) {
+    const float4 p = SRC.xyz[i];
+    const float ax = ((tf[0] * p.x + tf[1] * p.y) + tf[2] * p.z) + tf[3];
+    const float ay = ((tf[4] * p.x + tf[5] * p.y) + tf[6] * p.z) + tf[7];
+    const float az = ((tf[8] * p.x + tf[9] * p.y) + tf[10] * p.z) + tf[11];
+    if (!(isfinite(ax) && isfinite(ay) && isfinite(az))) acc[2] = 1.0;
+    const nnkey_t key = P.keys[i];
+    int j = -1;
+    if (key != NNKEY_NONE) {
+      acc[0] += (double)__uint_as_float((unsigned)(key >> 32));
+      acc[1] += 1.0;
+      j = (int)(key & 0xFFFFFFFFu);
+    }
+    if (i < S1.n && j >= 0) {
+      // normalised query point: pcl::transformPointCloud with diag(factor) and -factor*centroid
+      const float4 s = S1.xyz[i];
+      const double a0 = (double)(((fac * s.x + 0.f * s.y) + 0.f * s.z) + ox);
+      const double a1 = (double)(((0.f * s.x + fac * s.y) + 0.f * s.z) + oy);
+      const double a2 = (double)(((0.f * s.x + 0.f * s.y) + fac * s.z) + oz);
+      double n0 = 0, n1 = 0, n2 = 0;
+      if (j < S2.n) {
+        const float4 nn = S2.nrm[j];
+        n0 = nn.x;
+        n1 = nn.y;
+        n2 = nn.z;
+      }
+      const bool bad = isnan(a0) || isnan(a1) || isnan(a2) || isnan(n0) || isnan(n1) || isnan(n2);
+      if (!bad) {
+        const double r0 = R[0] * n0 + R[1] * n1 + R[2] * n2;
+        const double r1 = R[3] * n0 + R[4] * n1 + R[5] * n2;
+        const double r2 = R[6] * n0 + R[7] * n1 + R[8] * n2;
+        const double H[6] = {a1 * r2 - a2 * r1, a2 * r0 - a0 * r2, a0 * r1 - a1 * r0, r0, r1, r2};
+        int s_ = 3;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) acc[s_++] += H[r] * H[c];
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NPOST; ++i) {
+    const double v = wave_sum(acc[i]);
+    if (lane == 0) sh[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NPOST) {
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < RED_THREADS / 64; ++w) s += sh[w][threadIdx.x];
+    partials[((size_t)pair * RED_MAX_CHUNKS + bm.y) * NPOST + threadIdx.x] = s;
+  }
+}
+
+hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
+                              const int4* bmap, int n_blocks, double* partials,
+                              hipStream_t stream) {
+  if (n_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(post_reduce_kernel, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
+                     pairs, st, bmap, partials);
+  return hipGetLastError();
+}
+
+}  // namespace lgicp

@@ -1,0 +1,750 @@
+// lgicp_api.hip — host driver behind the C ABI of include/lamp_gicp.h.
+//
+// Mirrors the batch body of IcpLoopComputation::ComputeTransforms / PerformAlignment
+// (loop_closure/src/IcpLoopComputation.cc:243-367, 420-648): keyframe and pose registries
+// (first insert wins), per-candidate validity checks, scan accumulation, initial guess, the
+// GICP outer loop, fitness / transform gating, PoseInverse and the ICP covariance.  All
+// per-point work is enqueued as HIP kernels on one stream; all pairs of a batch advance
+// through the outer loop together and drop out individually as they converge.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lamp_gicp.h"
+#include "host_math.h"
+#include "lgicp_device.h"
+
+#include "lgicp_internal.h"
+
+namespace {
+
+inline int round_up(int n, int m) { return ((n + m - 1) / m) * m; }
+
+struct Arena {
+  lgicp_ctx* ctx;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(ctx->arena.p + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct CloudPlan {  // one distinct point cloud of a batch
+  uint64_t key;
+  bool accumulated;
+  std::vector<std::pair<uint64_t, hm::Pose>> segs;  // appended neighbour keyframes + tf
+  int n = 0, n_pad = 0;
+  bool need_norm_constants = false;
+};
+
+// XCD-aware order of workgroup ids: the dispatcher deals consecutive ids round-robin over the
+// 8 XCDs, so logical block (b % 8) * ceil(n/8) + b / 8 keeps neighbouring logical blocks (the
+// query tiles of one pair, which stream the same target) on one XCD's L2.
+template <typename T>
+void xcd_permute(std::vector<T>& v) {
+  const size_t n = v.size();
+  if (n < 16) return;
+  std::vector<T> out(n);
+  const size_t q = n / 8, r = n % 8;
+  for (size_t b = 0; b < n; ++b) {
+    const size_t x = b % 8, k = b / 8;
+    const size_t logical = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+    out[b] = v[logical];
+  }
+  v.swap(out);
+}
+
+}  // namespace
+
+extern "C" {
+
+void lgicp_default_config(lgicp_config* c, int base) {
+  std::memset(c, 0, sizeof(*c));
+  c->abi_version = LGICP_ABI_VERSION;
+  c->device = 0;
+  // loop_closure/config/laser_parameters.yaml, robot block :5-147, base block :153-301
+  c->tf_epsilon = 1e-10;
+  c->corr_dist = base ? 0.5 : 0.1;
+  c->iterations = base ? 200 : 5;
+  c->optimizer_iterations = 50;
+  c->rotation_epsilon = 2e-3;
+  c->k_correspondences = 20;
+  c->gicp_epsilon = 1e-3;
+  c->covariance_from_knn = 0;
+  c->init_method = LGICP_INIT_FEATURES;
+  c->covariance_method = LGICP_COV_POINT2PLANE;
+  c->max_tolerable_fitness = base ? 0.9 : 0.4;
+  c->transform_thresholding = base ? 1 : 0;
+  c->max_translation = 20;
+  c->max_rotation_deg = 50;
+  c->num_prev_scans = 2;
+  c->num_next_scans = 2;
+  c->accumulate_source = base ? 0 : 1;
+  c->laser_lc_rot_sigma = 0.01;
+  c->laser_lc_trans_sigma = 0.01;
+  c->use_fixed_covariances = 0;
+  c->sac_iterations = base ? 500 : 10;
+  c->sac_features_radius = 2.0;
+  c->sac_fitness_score_threshold = base ? 32.0 : 1.2;
+  c->harris_threshold = 0.000000005;
+  c->harris_suppression = 1;
+  c->harris_radius = 0.1;
+  c->harris_refine = 0;
+  c->harris_response = 1;
+  c->workspace_bytes = 0;
+}
+
+int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, LGICP_E_INVALID, "null argument");
+  if (cfg->abi_version != LGICP_ABI_VERSION)
+    return fail(nullptr, LGICP_E_INVALID, "abi_version %d != %d", cfg->abi_version,
+                LGICP_ABI_VERSION);
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(nullptr, LGICP_E_NO_DEVICE, "no HIP device visible");
+  if (cfg->device < 0 || cfg->device >= n_dev)
+    return fail(nullptr, LGICP_E_INVALID, "device %d out of range (%d devices)", cfg->device,
+                n_dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+    return fail(nullptr, LGICP_E_HIP, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, LGICP_E_NO_DEVICE, "device %d is %s, this library is built for gfx950",
+                cfg->device, prop.gcnArchName);
+  if (hipSetDevice(cfg->device) != hipSuccess)
+    return fail(nullptr, LGICP_E_HIP, "hipSetDevice failed");
+  lgicp_ctx* ctx = new lgicp_ctx();
+  ctx->cfg = *cfg;
+  std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+  if (ctx->cfg.workspace_bytes == 0) ctx->cfg.workspace_bytes = (size_t)16 << 30;
+  if (cfg->reserved[0] == 2 || cfg->reserved[0] == 4 || cfg->reserved[0] == 8)
+    ctx->nn_variant = cfg->reserved[0];
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->h_done, sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, LGICP_E_HIP, "stream / pinned allocation failed");
+  }
+  *out = ctx;
+  return LGICP_OK;
+}
+
+void lgicp_destroy(lgicp_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->cfg.device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->scans) {
+    if (kv.second.d_xyz) (void)hipFree(kv.second.d_xyz);
+    if (kv.second.d_nrm) (void)hipFree(kv.second.d_nrm);
+  }
+  ctx->arena.release();
+  ctx->d_clouds.release();
+  ctx->d_pairs.release();
+  ctx->d_state.release();
+  ctx->d_segs.release();
+  ctx->d_bmap_nn.release();
+  ctx->d_bmap_red.release();
+  ctx->d_ints.release();
+  ctx->d_partials.release();
+  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->h_done) (void)hipHostFree(ctx->h_done);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* lgicp_last_error(const lgicp_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const float* normals,
+                       size_t n, size_t stride_bytes) {
+  if (!ctx) return LGICP_E_INVALID;
+  if (n > 0 && !xyz) return fail(ctx, LGICP_E_INVALID, "xyz is null");
+  if (stride_bytes < 12 || stride_bytes % 4) return fail(ctx, LGICP_E_INVALID, "bad stride");
+  if (n > (size_t)1 << 28) return fail(ctx, LGICP_E_INVALID, "cloud too large");
+  if (ctx->scans.count(key)) return 0;  // first wins (IcpLoopComputation.cc:380-385)
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  Keyframe kf;
+  kf.n = (int)n;
+  kf.n_pad = std::max(NN_TILE, round_up((int)n, NN_TILE));
+  std::vector<float4> hx((size_t)kf.n_pad), hn(std::max<size_t>(n, 1));
+  const size_t sf = stride_bytes / 4;
+  for (size_t i = 0; i < n; ++i) {
+    hx[i] = make_float4(xyz[i * sf], xyz[i * sf + 1], xyz[i * sf + 2], 1.0f);
+    hn[i] = normals ? make_float4(normals[i * sf], normals[i * sf + 1], normals[i * sf + 2], 0.f)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (size_t i = n; i < (size_t)kf.n_pad; ++i)
+    hx[i] = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 1.0f);
+  HIP_TRY(ctx, hipMalloc((void**)&kf.d_xyz, sizeof(float4) * (size_t)kf.n_pad));
+  HIP_TRY(ctx, hipMalloc((void**)&kf.d_nrm, sizeof(float4) * std::max<size_t>(n, 1)));
+  HIP_TRY(ctx, hipMemcpy(kf.d_xyz, hx.data(), sizeof(float4) * (size_t)kf.n_pad,
+                         hipMemcpyHostToDevice));
+  if (n)
+    HIP_TRY(ctx, hipMemcpy(kf.d_nrm, hn.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+  ctx->scans.emplace(key, kf);
+  return 1;
+}
+
+int lgicp_add_pose(lgicp_ctx* ctx, uint64_t key, const double q[4], const double t[3]) {
+  if (!ctx || !q || !t) return LGICP_E_INVALID;
+  if (ctx->poses.count(key)) return 0;  // first wins (IcpLoopComputation.cc:400-402)
+  ctx->poses.emplace(key, hm::pose_from_quat(q, t));
+  return 1;
+}
+
+int lgicp_has_keyframe(const lgicp_ctx* ctx, uint64_t key) {
+  return ctx && ctx->scans.count(key) ? 1 : 0;
+}
+int lgicp_has_pose(const lgicp_ctx* ctx, uint64_t key) {
+  return ctx && ctx->poses.count(key) ? 1 : 0;
+}
+
+int lgicp_get_stats(const lgicp_ctx* ctx, lgicp_stats* out) {
+  if (!ctx || !out) return LGICP_E_INVALID;
+  *out = ctx->stats;
+  return LGICP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct PairPlan {
+  size_t cand;  // index into the caller's arrays
+  int src_cloud, tgt_cloud, scan1_cloud, scan2_cloud;
+  float guess[16];
+  hm::Pose pose21_odom;
+};
+
+struct BatchPlan {
+  std::vector<CloudPlan> clouds;
+  std::map<std::pair<uint64_t, int>, int> cloud_index;
+  std::vector<PairPlan> pairs;
+  size_t bytes = 0;
+};
+
+int plan_cloud(lgicp_ctx* ctx, BatchPlan& bp, uint64_t key, bool accumulate) {
+  // AccumulateScans (IcpLoopComputation.cc:910-947): prev keys key-1.. then next keys key+1..;
+  // a neighbour is used only when both its scan and its pose exist
+  std::vector<std::pair<uint64_t, hm::Pose>> segs;
+  if (accumulate) {
+    const hm::Pose& new_pose = ctx->poses.at(key);
+    for (int i = 0; i < ctx->cfg.num_prev_scans; ++i) {
+      const uint64_t k = key - (uint64_t)i - 1;
+      if (!ctx->poses.count(k) || !ctx->scans.count(k)) continue;
+      segs.emplace_back(k, hm::between(new_pose, ctx->poses.at(k)));
+    }
+    for (int i = 0; i < ctx->cfg.num_next_scans; ++i) {
+      const uint64_t k = key + (uint64_t)i + 1;
+      if (!ctx->poses.count(k) || !ctx->scans.count(k)) continue;
+      segs.emplace_back(k, hm::between(new_pose, ctx->poses.at(k)));
+    }
+  }
+  const bool acc = !segs.empty();
+  auto id = std::make_pair(key, acc ? 1 : 0);
+  auto it = bp.cloud_index.find(id);
+  if (it != bp.cloud_index.end()) return it->second;
+  CloudPlan cp;
+  cp.key = key;
+  cp.accumulated = acc;
+  cp.segs = std::move(segs);
+  cp.n = ctx->scans.at(key).n;
+  for (auto& s : cp.segs) cp.n += ctx->scans.at(s.first).n;
+  cp.n_pad = std::max(NN_TILE, round_up(cp.n, NN_TILE));
+  bp.bytes += (size_t)cp.n * 48 + 256;                              // covariances
+  if (acc) bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 16 + 512;  // xyz + normals
+  const int idx = (int)bp.clouds.size();
+  bp.clouds.push_back(std::move(cp));
+  bp.cloud_index[id] = idx;
+  return idx;
+}
+
+void guess_from_pose(const hm::Pose& p, bool with_translation, float g[16]) {
+  for (int i = 0; i < 16; ++i) g[i] = (i % 5 == 0) ? 1.f : 0.f;
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) g[a * 4 + b] = (float)p.R[a * 3 + b];
+    if (with_translation) g[a * 4 + 3] = (float)p.t[a];
+  }
+}
+
+// runs one device batch; results for bp.pairs[i] go to out[bp.pairs[i].cand]
+int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_result* out) {
+  const lgicp_config& cfg = ctx->cfg;
+  hipStream_t st = ctx->stream;
+  const int n_pairs = (int)bp.pairs.size();
+  const int n_clouds = (int)bp.clouds.size();
+  if (n_pairs == 0) return LGICP_OK;
+
+  // ---- device scratch ----------------------------------------------------------------------
+  size_t pair_bytes = 0;
+  for (auto& p : bp.pairs) pair_bytes += (size_t)bp.clouds[p.src_cloud].n * 24 + 512;
+  HIP_TRY(ctx, ctx->arena.reserve(bp.bytes + pair_bytes + 4096));
+  Arena ar{ctx};
+
+  std::vector<CloudDev> h_clouds((size_t)n_clouds);
+  std::vector<SegmentDev> h_segs;
+  int max_seg_n = 0, max_cloud_n = 0;
+  for (int c = 0; c < n_clouds; ++c) {
+    CloudPlan& cp = bp.clouds[c];
+    const Keyframe& kf = ctx->scans.at(cp.key);
+    CloudDev& cd = h_clouds[c];
+    std::memset(&cd, 0, sizeof(cd));
+    cd.n = cp.n;
+    cd.n_pad = cp.n_pad;
+    cd.cov = ar.take<double>((size_t)cp.n * 6);
+    max_cloud_n = std::max(max_cloud_n, cp.n);
+    if (!cp.accumulated) {
+      cd.xyz = kf.d_xyz;
+      cd.nrm = kf.d_nrm;
+    } else {
+      float4* xyz = ar.take<float4>((size_t)cp.n_pad);
+      float4* nrm = ar.take<float4>((size_t)cp.n);
+      cd.xyz = xyz;
+      cd.nrm = nrm;
+      int off = 0;
+      SegmentDev s;
+      std::memset(&s, 0, sizeof(s));
+      s.src_xyz = kf.d_xyz;
+      s.src_nrm = kf.d_nrm;
+      s.dst_xyz = xyz;
+      s.dst_nrm = nrm;
+      s.n = kf.n;
+      s.identity = 1;
+      h_segs.push_back(s);
+      max_seg_n = std::max(max_seg_n, s.n);
+      off += kf.n;
+      for (auto& sg : cp.segs) {
+        const Keyframe& nk = ctx->scans.at(sg.first);
+        std::memset(&s, 0, sizeof(s));
+        s.src_xyz = nk.d_xyz;
+        s.src_nrm = nk.d_nrm;
+        s.dst_xyz = xyz + off;
+        s.dst_nrm = nrm + off;
+        s.n = nk.n;
+        s.identity = 0;
+        for (int a = 0; a < 3; ++a) {
+          for (int b = 0; b < 3; ++b) s.T[a * 4 + b] = sg.second.R[a * 3 + b];
+          s.T[a * 4 + 3] = sg.second.t[a];
+        }
+        h_segs.push_back(s);
+        max_seg_n = std::max(max_seg_n, s.n);
+        off += nk.n;
+      }
+    }
+  }
+
+  std::vector<PairDev> h_pairs((size_t)n_pairs);
+  std::vector<PairState> h_state((size_t)n_pairs);
+  int max_src_n = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    const PairPlan& pp = bp.pairs[p];
+    PairDev& pd = h_pairs[p];
+    std::memset(&pd, 0, sizeof(pd));
+    pd.src_cloud = pp.src_cloud;
+    pd.tgt_cloud = pp.tgt_cloud;
+    pd.scan1_cloud = pp.scan1_cloud;
+    pd.scan2_cloud = pp.scan2_cloud;
+    pd.n_src = bp.clouds[pp.src_cloud].n;
+    pd.n_tgt = bp.clouds[pp.tgt_cloud].n;
+    pd.out = ar.take<float4>((size_t)pd.n_src);
+    pd.keys = ar.take<nnkey_t>((size_t)pd.n_src);
+    std::memcpy(pd.guess, pp.guess, sizeof(pd.guess));
+    max_src_n = std::max(max_src_n, pd.n_src);
+    PairState& s = h_state[p];
+    std::memset(&s, 0, sizeof(s));
+    for (int i = 0; i < 16; ++i) s.T[i] = s.Tprev[i] = s.Tfinal[i] = (i % 5 == 0) ? 1.f : 0.f;
+    s.active = 1;
+    // computeCovariances returns early when a cloud is smaller than k_correspondences_
+    // (gicp.hpp:72-79; k is lowered to |source| for sources under 20 points,
+    // IcpLoopComputation.cc:487-489).  The reference then reads an empty covariance vector;
+    // here such a pair ends unconverged.
+    const int k_eff = pd.n_src < 20 ? pd.n_src : cfg.k_correspondences;
+    if (k_eff > pd.n_src || k_eff > pd.n_tgt) {
+      s.active = 0;
+      s.failed = 1;
+      std::memcpy(s.Tfinal, pd.guess, sizeof(s.Tfinal));
+    }
+  }
+
+  // ---- block maps ----------------------------------------------------------------------------
+  const int QB = nn_queries_per_block(ctx->nn_variant);
+  long long base_blocks = 0;
+  for (auto& pd : h_pairs) base_blocks += (pd.n_src + QB - 1) / QB;
+  int splits = 1;
+  {
+    const int forced = cfg.reserved[1];
+    if (forced > 0)
+      splits = forced;
+    else
+      while (base_blocks * splits < 1024 && splits < 64) splits *= 2;
+  }
+  std::vector<int4> h_bmap_nn, h_bmap_red;
+  std::vector<int> h_ints((size_t)2 * n_pairs + 4, 0);
+  double evals_per_pass = 0;
+  bool any_split = false;
+  for (int p = 0; p < n_pairs; ++p) {
+    const PairDev& pd = h_pairs[p];
+    const int tiles = bp.clouds[bp.pairs[p].tgt_cloud].n_pad / NN_TILE;
+    const int sp = std::max(1, std::min(splits, tiles));
+    any_split |= sp > 1;
+    const int qt = (pd.n_src + QB - 1) / QB;
+    for (int t = 0; t < qt; ++t)
+      for (int s = 0; s < sp; ++s) h_bmap_nn.push_back(make_int4(p, t, s, sp));
+    int chunks = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + 4095) / 4096));
+    h_ints[p] = chunks;
+    for (int c = 0; c < chunks; ++c) h_bmap_red.push_back(make_int4(p, c, chunks, 0));
+    evals_per_pass += (double)pd.n_src * (double)pd.n_tgt;
+  }
+  xcd_permute(h_bmap_nn);
+  std::vector<int> scan1_ids;
+  for (int c = 0; c < n_clouds; ++c)
+    if (bp.clouds[c].need_norm_constants) scan1_ids.push_back(c);
+  for (size_t i = 0; i < scan1_ids.size(); ++i) h_ints.push_back(scan1_ids[i]);
+  const size_t off_ids = (size_t)2 * n_pairs + 4;
+  const size_t off_done = (size_t)n_pairs;  // n_done lives right after n_chunks
+
+  HIP_TRY(ctx, ctx->d_clouds.reserve(n_clouds));
+  HIP_TRY(ctx, ctx->d_pairs.reserve(n_pairs));
+  HIP_TRY(ctx, ctx->d_state.reserve(n_pairs));
+  HIP_TRY(ctx, ctx->d_segs.reserve(std::max<size_t>(h_segs.size(), 1)));
+  HIP_TRY(ctx, ctx->d_bmap_nn.reserve(h_bmap_nn.size()));
+  HIP_TRY(ctx, ctx->d_bmap_red.reserve(h_bmap_red.size()));
+  HIP_TRY(ctx, ctx->d_ints.reserve(h_ints.size()));
+  HIP_TRY(ctx, ctx->d_partials.reserve((size_t)n_pairs * RED_MAX_CHUNKS * NSTAT));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_clouds.p, h_clouds.data(), sizeof(CloudDev) * n_clouds,
+                              hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
+                              hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state.p, h_state.data(), sizeof(PairState) * n_pairs,
+                              hipMemcpyHostToDevice, st));
+  if (!h_segs.empty())
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_segs.p, h_segs.data(), sizeof(SegmentDev) * h_segs.size(),
+                                hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size(),
+                              hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
+                              sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ints.p, h_ints.data(), sizeof(int) * h_ints.size(),
+                              hipMemcpyHostToDevice, st));
+  // the host vectors above must outlive the copies
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+
+  ctx->ev_used = 0;
+  hipEvent_t ev_begin = ctx->event(), ev_prep = ctx->event();
+  HIP_TRY(ctx, hipEventRecord(ev_begin, st));
+
+  // ---- clouds: accumulate, pad, covariances, normalisation constants --------------------------
+  HIP_TRY(ctx, launch_assemble(ctx->d_segs.p, (int)h_segs.size(), max_seg_n, st));
+  for (int c = 0; c < n_clouds; ++c)
+    if (bp.clouds[c].accumulated)
+      HIP_TRY(ctx, launch_pad_fill(const_cast<float4*>(h_clouds[c].xyz), h_clouds[c].n,
+                                   h_clouds[c].n_pad, st));
+  if (cfg.covariance_from_knn) {
+    for (int c = 0; c < n_clouds; ++c)
+      HIP_TRY(ctx, launch_cov_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
+                                  cfg.k_correspondences, cfg.gicp_epsilon,
+                                  const_cast<double*>(h_clouds[c].cov), st));
+  } else {
+    for (int c = 0; c < n_clouds; ++c)
+      HIP_TRY(ctx, launch_cov_from_normals(h_clouds[c].nrm, h_clouds[c].n,
+                                           const_cast<double*>(h_clouds[c].cov), st));
+  }
+  HIP_TRY(ctx, launch_normalize_constants(ctx->d_clouds.p, ctx->d_ints.p + off_ids,
+                                          (int)scan1_ids.size(), st));
+  HIP_TRY(ctx, launch_guess_transform(ctx->d_clouds.p, ctx->d_pairs.p, n_pairs, max_src_n, st));
+  HIP_TRY(ctx, hipEventRecord(ev_prep, st));
+
+  // ---- GICP outer loop -----------------------------------------------------------------------
+  SolveParams sp;
+  sp.corr_dist2 = cfg.corr_dist * cfg.corr_dist;
+  sp.rotation_epsilon = cfg.rotation_epsilon;
+  sp.tf_epsilon = cfg.tf_epsilon;
+  sp.max_iterations = cfg.iterations;
+  sp.max_inner_iterations = cfg.optimizer_iterations;
+  int* d_done = ctx->d_ints.p + off_done;
+  int n_inactive0 = 0;
+  for (auto& s : h_state) n_inactive0 += s.active ? 0 : 1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_ev, red_ev, sol_ev;
+  int outer = 0;
+  ctx->h_done[0] = 0;
+  while (n_inactive0 + ctx->h_done[0] < n_pairs && outer < cfg.iterations + 1) {
+    hipEvent_t a = ctx->event(), b = ctx->event(), c = ctx->event(), d = ctx->event();
+    HIP_TRY(ctx, hipEventRecord(a, st));
+    if (any_split)
+      HIP_TRY(ctx, launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, false, st));
+    HIP_TRY(ctx, launch_nn_search(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
+                                  ctx->d_bmap_nn.p, (int)h_bmap_nn.size(), false, any_split,
+                                  ctx->nn_variant, st));
+    HIP_TRY(ctx, hipEventRecord(b, st));
+    HIP_TRY(ctx, launch_gicp_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
+                                    ctx->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
+                                    ctx->d_partials.p, st));
+    HIP_TRY(ctx, hipEventRecord(c, st));
+    HIP_TRY(ctx, launch_gicp_solve(ctx->d_pairs.p, ctx->d_state.p, n_pairs, ctx->d_ints.p,
+                                   ctx->d_partials.p, sp, d_done, st));
+    HIP_TRY(ctx, hipEventRecord(d, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_done, d_done, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    nn_ev.emplace_back(a, b);
+    red_ev.emplace_back(b, c);
+    sol_ev.emplace_back(c, d);
+    ++outer;
+  }
+
+  // ---- final pass: fitness + correspondences + Ap ----------------------------------------------
+  hipEvent_t ev_post0 = ctx->event(), ev_post1 = ctx->event(), ev_post2 = ctx->event();
+  HIP_TRY(ctx, hipEventRecord(ev_post0, st));
+  if (any_split)
+    HIP_TRY(ctx, launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, true, st));
+  HIP_TRY(ctx, launch_nn_search(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, ctx->d_bmap_nn.p,
+                                (int)h_bmap_nn.size(), true, any_split, ctx->nn_variant, st));
+  HIP_TRY(ctx, hipEventRecord(ev_post1, st));
+  HIP_TRY(ctx, launch_post_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
+                                  ctx->d_bmap_red.p, (int)h_bmap_red.size(), ctx->d_partials.p,
+                                  st));
+  HIP_TRY(ctx, hipEventRecord(ev_post2, st));
+  std::vector<double> h_post((size_t)n_pairs * RED_MAX_CHUNKS * NPOST);
+  HIP_TRY(ctx, hipMemcpyAsync(h_post.data(), ctx->d_partials.p, sizeof(double) * h_post.size(),
+                              hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(h_state.data(), ctx->d_state.p, sizeof(PairState) * n_pairs,
+                              hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+
+  // ---- timing ------------------------------------------------------------------------------
+  auto sum_ms = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+    double s = 0;
+    for (auto& e : v) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) s += ms;
+    }
+    return s;
+  };
+  float ms = 0;
+  lgicp_stats& S = ctx->stats;
+  const double nn_loop_ms = sum_ms(nn_ev);
+  (void)hipEventElapsedTime(&ms, ev_post0, ev_post1);
+  const double nn_final_ms = ms;
+  S.nn_ms += nn_loop_ms + nn_final_ms;
+  S.reduce_ms += sum_ms(red_ev);
+  S.solve_ms += sum_ms(sol_ev);
+  (void)hipEventElapsedTime(&ms, ev_begin, ev_prep);
+  S.cov_ms += ms;
+  (void)hipEventElapsedTime(&ms, ev_post1, ev_post2);
+  S.post_ms += ms;
+  (void)hipEventElapsedTime(&ms, ev_begin, ev_post2);
+  S.total_ms += ms;
+  S.nn_launches += (uint64_t)outer + 1;
+  // the final pass always covers every pair of the batch: it is the launch the roofline uses
+  S.last_nn_kernel_ms = nn_final_ms;
+  S.last_nn_evals_per_launch = evals_per_pass;
+
+  // ---- per-pair host post-processing (IcpLoopComputation.cc:568-640) -----------------------------
+  for (int p = 0; p < n_pairs; ++p) {
+    const PairPlan& pp = bp.pairs[p];
+    const PairState& s = h_state[p];
+    lgicp_result& r = out[pp.cand];
+    r.iterations = s.iterations;
+    r.converged = s.converged;
+    r.n_correspondences = s.m;
+    std::memcpy(r.T_icp, s.Tfinal, sizeof(r.T_icp));
+    S.outer_iterations += (uint64_t)s.iterations;
+    S.nn_distance_evals +=
+        (double)h_pairs[p].n_src * (double)h_pairs[p].n_tgt * (double)(s.iterations + 1);
+    double post[NPOST] = {0};
+    for (int c = 0; c < h_ints[p]; ++c)
+      for (int k = 0; k < NPOST; ++k) post[k] += h_post[((size_t)p * RED_MAX_CHUNKS + c) * NPOST + k];
+    const float* T = s.Tfinal;
+    bool finite = post[2] == 0.0;
+    for (int i = 0; i < 16; ++i) finite = finite && std::isfinite(T[i]);
+    if (cfg.covariance_method == LGICP_COV_POINT2PLANE && !finite) {
+      r.status = LGICP_PAIR_NONFINITE;
+      continue;
+    }
+    hm::Pose delta;
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) delta.R[a * 3 + b] = (double)T[a * 4 + b];
+      delta.t[a] = (double)T[a * 4 + 3];
+    }
+    r.fitness = post[1] > 0 ? post[0] / post[1] : 1.7976931348623157e308;
+    if (!s.converged) {
+      r.status = LGICP_PAIR_NOT_CONVERGED;
+      continue;
+    }
+    if (r.fitness > cfg.max_tolerable_fitness) {
+      r.status = LGICP_PAIR_FITNESS;
+      continue;
+    }
+    {
+      double xi[6];
+      hm::logmap(hm::between(pp.pose21_odom, delta), xi);
+      const double trans_diff = std::sqrt(xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5]);
+      const double rot_diff = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
+      if (cfg.transform_thresholding &&
+          (trans_diff > cfg.max_translation || rot_diff > cfg.max_rotation_deg * M_PI / 180.0)) {
+        r.status = LGICP_PAIR_TRANSFORM;
+        continue;
+      }
+    }
+    const hm::Pose inv = hm::inverse(delta);
+    std::memcpy(r.delta_R, inv.R, sizeof(r.delta_R));
+    std::memcpy(r.delta_t, inv.t, sizeof(r.delta_t));
+    hm::quat_from_R(inv.R, r.delta_q);
+    double Ap[36];
+    {
+      int k = 3;
+      for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) Ap[a * 6 + b] = Ap[b * 6 + a] = post[k++];
+    }
+    if (cfg.use_fixed_covariances) {
+      hm::fixed_covariance(cfg.laser_lc_rot_sigma, cfg.laser_lc_trans_sigma, r.covariance);
+      hm::inverse6(r.covariance, r.information);
+    } else {
+      hm::point_plane_covariance(Ap, cfg.laser_lc_rot_sigma, cfg.laser_lc_trans_sigma,
+                                 r.covariance);
+      for (int i = 0; i < 36; ++i) r.information[i] = Ap[i] / (0.05 * 0.05);
+    }
+    r.status = LGICP_PAIR_OK;
+    S.pairs_ok++;
+  }
+  return LGICP_OK;
+}
+
+}  // namespace
+
+extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n,
+                            lgicp_result* out) {
+  if (!ctx) return LGICP_E_INVALID;
+  if (n && (!cand || !out)) return fail(ctx, LGICP_E_INVALID, "null argument");
+  const lgicp_config& cfg = ctx->cfg;
+  if (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP)
+    return fail(ctx, LGICP_E_UNSUPPORTED,
+                "init_method %d (feature-based initial alignment) is not available on the device "
+                "path yet",
+                cfg.init_method);
+  if (cfg.covariance_method == LGICP_COV_POINT2POINT && !cfg.use_fixed_covariances)
+    return fail(ctx, LGICP_E_UNSUPPORTED, "POINT2POINT covariance is not available yet");
+  HIP_TRY(ctx, hipSetDevice(cfg.device));
+  ctx->stats.nn_ms = ctx->stats.reduce_ms = ctx->stats.solve_ms = ctx->stats.cov_ms =
+      ctx->stats.post_ms = ctx->stats.total_ms = 0;
+
+  size_t i = 0;
+  while (i < n) {
+    BatchPlan bp;
+    size_t pair_bytes = 0;
+    for (; i < n; ++i) {
+      const lgicp_candidate& c = cand[i];
+      lgicp_result& r = out[i];
+      std::memset(&r, 0, sizeof(r));
+      r.key_from = c.key_from;
+      r.key_to = c.key_to;
+      ctx->stats.pairs_submitted++;
+      // PerformAlignment's availability checks (IcpLoopComputation.cc:438-465)
+      if (!ctx->scans.count(c.key_from) || !ctx->scans.count(c.key_to)) {
+        r.status = LGICP_PAIR_MISSING_SCAN;
+        continue;
+      }
+      if (!ctx->poses.count(c.key_from) || !ctx->poses.count(c.key_to)) {
+        r.status = LGICP_PAIR_MISSING_POSE;
+        continue;
+      }
+      if (ctx->scans.at(c.key_from).n == 0 || ctx->scans.at(c.key_to).n == 0) {
+        r.status = LGICP_PAIR_EMPTY_CLOUD;
+        continue;
+      }
+      const size_t est = (size_t)ctx->scans.at(c.key_from).n * 24 * (cfg.accumulate_source ? 5 : 1);
+      if (!bp.pairs.empty() && bp.bytes + pair_bytes + est > cfg.workspace_bytes) break;
+      PairPlan pp;
+      pp.cand = i;
+      pp.tgt_cloud = plan_cloud(ctx, bp, c.key_to, true);
+      pp.src_cloud = plan_cloud(ctx, bp, c.key_from, cfg.accumulate_source != 0);
+      pp.scan1_cloud = plan_cloud(ctx, bp, c.key_from, false);
+      pp.scan2_cloud = plan_cloud(ctx, bp, c.key_to, false);
+      bp.clouds[pp.scan1_cloud].need_norm_constants = true;
+      // initial guess (IcpLoopComputation.cc:495-543)
+      pp.pose21_odom = hm::between(ctx->poses.at(c.key_to), ctx->poses.at(c.key_from));
+      switch (cfg.init_method) {
+        case LGICP_INIT_ODOMETRY: guess_from_pose(pp.pose21_odom, true, pp.guess); break;
+        case LGICP_INIT_ODOM_ROTATION: guess_from_pose(pp.pose21_odom, false, pp.guess); break;
+        case LGICP_INIT_CANDIDATE: {
+          const hm::Pose p1 = hm::pose_from_quat(c.pose_from_q, c.pose_from_t);
+          const hm::Pose p2 = hm::pose_from_quat(c.pose_to_q, c.pose_to_t);
+          guess_from_pose(hm::between(p2, p1), true, pp.guess);
+        } break;
+        default:
+          for (int k = 0; k < 16; ++k) pp.guess[k] = (k % 5 == 0) ? 1.f : 0.f;
+      }
+      pair_bytes += (size_t)bp.clouds[pp.src_cloud].n * 24 + 512;
+      bp.pairs.push_back(pp);
+    }
+    const int rc = run_batch(ctx, bp, cand, out);
+    if (rc != LGICP_OK) return rc;
+  }
+  return LGICP_OK;
+}
+
+// One alignment with an explicit guess: the two clouds become temporary keyframes (keys far
+// from any neighbour, so nothing is accumulated) and go through the same batch path.
+extern "C" int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* src_normals,
+                           size_t n_src, const float* tgt_xyz, const float* tgt_normals,
+                           size_t n_tgt, const float guess[16], float final_T[16], int* converged,
+                           int* iterations, double* fitness) {
+  if (!ctx || !guess || !final_T) return fail(ctx, LGICP_E_INVALID, "null argument");
+  if (n_src == 0 || n_tgt == 0) return fail(ctx, LGICP_E_INVALID, "empty cloud");
+  const uint64_t ks = 0xFFFFFFF000000000ull, kt = 0xFFFFFFE000000000ull;
+  if (ctx->scans.count(ks) || ctx->scans.count(kt))
+    return fail(ctx, LGICP_E_INVALID, "reserved keys in use");
+  int rc = lgicp_add_keyframe(ctx, ks, src_xyz, src_normals, n_src, 12);
+  if (rc < 0) return rc;
+  rc = lgicp_add_keyframe(ctx, kt, tgt_xyz, tgt_normals, n_tgt, 12);
+  if (rc >= 0) {
+    const double q[4] = {1, 0, 0, 0}, t[3] = {0, 0, 0};
+    ctx->poses.emplace(ks, hm::pose_from_quat(q, t));
+    ctx->poses.emplace(kt, hm::pose_from_quat(q, t));
+    BatchPlan bp;
+    PairPlan pp;
+    pp.cand = 0;
+    pp.tgt_cloud = plan_cloud(ctx, bp, kt, false);
+    pp.src_cloud = plan_cloud(ctx, bp, ks, false);
+    pp.scan1_cloud = pp.src_cloud;
+    pp.scan2_cloud = pp.tgt_cloud;
+    bp.clouds[pp.scan1_cloud].need_norm_constants = true;
+    pp.pose21_odom = hm::pose_from_quat(q, t);
+    std::memcpy(pp.guess, guess, sizeof(pp.guess));
+    bp.pairs.push_back(pp);
+    lgicp_candidate c;
+    std::memset(&c, 0, sizeof(c));
+    lgicp_result r;
+    std::memset(&r, 0, sizeof(r));
+    ctx->stats.nn_ms = ctx->stats.reduce_ms = ctx->stats.solve_ms = ctx->stats.cov_ms =
+        ctx->stats.post_ms = ctx->stats.total_ms = 0;
+    rc = hipSetDevice(ctx->cfg.device) == hipSuccess ? run_batch(ctx, bp, &c, &r) : LGICP_E_HIP;
+    if (rc == LGICP_OK) {
+      std::memcpy(final_T, r.T_icp, sizeof(r.T_icp));
+      if (converged) *converged = r.converged;
+      if (iterations) *iterations = r.iterations;
+      if (fitness) *fitness = r.fitness;
+    }
+  }
+  for (uint64_t k : {ks, kt}) {
+    auto it = ctx->scans.find(k);
+    if (it != ctx->scans.end()) {
+      if (it->second.d_xyz) (void)hipFree(it->second.d_xyz);
+      if (it->second.d_nrm) (void)hipFree(it->second.d_nrm);
+      ctx->scans.erase(it);
+    }
+    ctx->poses.erase(k);
+  }
+  return rc < 0 ? rc : LGICP_OK;
+}

@@ -1,0 +1,121 @@
+// lgicp_device.h — structures shared by the HIP kernels and the host driver of the
+// MI355X loop-closure verification engine.  gfx950 only (64-wide wavefronts).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lgicp {
+
+// Packed (squared distance, target index) of a 1-NN result.  d2 >= 0, so its float bits
+// order like the value; min over the 64-bit key = smallest distance, lowest index on ties.
+typedef unsigned long long nnkey_t;
+static constexpr nnkey_t NNKEY_NONE = 0xFFFFFFFFFFFFFFFFull;
+
+// coordinate of the points that pad a target cloud up to a whole LDS tile: far enough that
+// its squared distance (~3e36) never beats a real point, small enough not to overflow
+static constexpr float PAD_COORD = 1.0e18f;
+
+static constexpr int NN_THREADS = 256;
+static constexpr int NN_TILE = 1024;  // target points per LDS tile (12 KiB as SoA floats)
+static constexpr int NN_GROUP = 8;    // targets whose minimum is tracked together
+
+// number of f64 statistics per pair and outer iteration: 10 x 6 second moments
+// sum(u_k u_l M), 4 x 3 first moments sum(u_k M r0), sum(r0^T M r0), correspondence count
+static constexpr int NSTAT = 74;
+static constexpr int RED_THREADS = 256;
+static constexpr int RED_MAX_CHUNKS = 16;
+
+// fitness sum, count, non-finite flag, 21 unique entries of Ap
+static constexpr int NPOST = 24;
+
+struct CloudDev {
+  const float4* xyz;  // n_pad points (x, y, z, 1), tail = PAD_COORD
+  const float4* nrm;  // n normals (x, y, z, 0)
+  const double* cov;  // n x 6: c00 c01 c02 c11 c12 c22
+  int n;
+  int n_pad;
+  // NormalizePCloud constants (used only for the un-accumulated source keyframe)
+  float centroid[3];
+  float factor;
+};
+
+struct PairDev {
+  int src_cloud;    // accumulated source
+  int tgt_cloud;    // accumulated target
+  int scan1_cloud;  // un-accumulated source keyframe (query of the POINT2PLANE covariance)
+  int scan2_cloud;  // un-accumulated target keyframe (normals of the POINT2PLANE covariance)
+  float4* out;      // guess * source, n_src points
+  nnkey_t* keys;    // n_src packed 1-NN results
+  float guess[16];
+  int n_src;
+  int n_tgt;
+};
+
+struct PairState {
+  float T[16];       // transformation_
+  float Tprev[16];   // previous_transformation_
+  float Tfinal[16];  // previous_ * guess
+  double delta;
+  int iterations;
+  int converged;
+  int active;  // still inside the outer loop
+  int failed;  // optimiser "exception" (fewer than 4 correspondences)
+  int m;       // correspondences of the last outer iteration
+  int pad;
+};
+
+struct SolveParams {
+  double corr_dist2;
+  double rotation_epsilon;
+  double tf_epsilon;
+  int max_iterations;
+  int max_inner_iterations;
+};
+
+// ---- launchers (each enqueues on `stream`, returns the hipError_t of the launch) ----------
+
+hipError_t launch_pad_fill(float4* xyz, int n, int n_pad, hipStream_t stream);
+hipError_t launch_cov_from_normals(const float4* nrm, int n, double* cov6, hipStream_t stream);
+
+struct SegmentDev {  // one keyframe appended to an accumulated cloud
+  const float4* src_xyz;
+  const float4* src_nrm;
+  float4* dst_xyz;
+  float4* dst_nrm;
+  double T[12];  // row-major 3x4, applied in double then cast (transformPointCloud<double>)
+  int n;
+  int identity;  // 1: plain copy (the key's own scan)
+};
+hipError_t launch_assemble(const SegmentDev* segs, int n_segs, int max_n, hipStream_t stream);
+
+hipError_t launch_guess_transform(const CloudDev* clouds, const PairDev* pairs, int n_pairs,
+                                  int max_n, hipStream_t stream);
+hipError_t launch_normalize_constants(CloudDev* clouds, const int* cloud_ids, int n_ids,
+                                      hipStream_t stream);
+
+// bmap entry: x = pair, y = query tile, z = split, w = number of splits
+hipError_t launch_nn_search(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
+                            const int4* bmap, int n_blocks, bool final_pass, bool any_split,
+                            int variant, hipStream_t stream);
+int nn_queries_per_block(int variant);
+hipError_t launch_keys_fill(const PairDev* pairs, const PairState* st, int n_pairs, int max_n,
+                            bool final_pass, hipStream_t stream);
+hipError_t launch_keys_unpack(const nnkey_t* keys, int n, int32_t* idx, float* d2,
+                              hipStream_t stream);
+
+// bmap entry: x = pair, y = chunk, z = number of chunks
+hipError_t launch_gicp_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
+                              const int4* bmap, int n_blocks, double corr_dist2, double* partials,
+                              hipStream_t stream);
+hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
+                             const int* n_chunks, const double* partials, SolveParams sp,
+                             int* n_done, hipStream_t stream);
+hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
+                              const int4* bmap, int n_blocks, double* partials,
+                              hipStream_t stream);
+
+hipError_t launch_cov_knn(const float4* xyz, int n, int n_pad, int k, double eps, double* cov6,
+                          hipStream_t stream);
+
+}  // namespace lgicp

@@ -1,0 +1,108 @@
+// lgicp_internal.h — context object and helpers shared by the host translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lamp_gicp.h"
+#include "host_math.h"
+#include "lgicp_device.h"
+
+using namespace lgicp;
+
+namespace lgicp_detail {
+
+inline std::string g_create_error;
+
+struct Keyframe {
+  int n = 0;
+  int n_pad = 0;
+  float4* d_xyz = nullptr;  // n_pad
+  float4* d_nrm = nullptr;  // n
+};
+
+template <typename T>
+struct DevBuf {  // grow-only device array
+  T* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 16;
+    hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace lgicp_detail
+using namespace lgicp_detail;
+
+struct lgicp_ctx {
+  lgicp_config cfg;
+  hipStream_t stream = nullptr;
+  std::unordered_map<uint64_t, Keyframe> scans;
+  std::unordered_map<uint64_t, hm::Pose> poses;
+  std::string err;
+  lgicp_stats stats;
+  int nn_variant = 4;
+
+  DevBuf<char> arena;  // per-batch scratch (bump allocated)
+  size_t arena_off = 0;
+  DevBuf<CloudDev> d_clouds;
+  DevBuf<PairDev> d_pairs;
+  DevBuf<PairState> d_state;
+  DevBuf<SegmentDev> d_segs;
+  DevBuf<int4> d_bmap_nn, d_bmap_red;
+  DevBuf<int> d_ints;  // n_chunks[n_pairs] | scan1 ids | n_done
+  DevBuf<double> d_partials;
+  int* h_done = nullptr;  // pinned
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+
+  hipEvent_t event() {
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      ev_pool.push_back(e);
+    }
+    return ev_pool[ev_used++];
+  }
+};
+
+namespace lgicp_detail {
+
+inline int fail(lgicp_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                    \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return fail(ctx, LGICP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),    \
+                  __FILE__, __LINE__);                                                        \
+  } while (0)
+
+}  // namespace lgicp_detail

@@ -1,0 +1,214 @@
+// lgicp_primitives.hip — kernel-level entry points of the C ABI (host buffers in and out).
+// Each one uploads its operands, runs exactly the kernel the batch path runs, and downloads
+// the result; they exist so that every kernel can be checked on its own.
+#include <algorithm>
+#include <cstring>
+
+#include "lgicp_internal.h"
+
+namespace {
+
+struct Dev {  // frees everything it handed out
+  std::vector<void*> ptrs;
+  ~Dev() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  T* alloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return (T*)p;
+  }
+};
+
+inline int round_up(int n, int m) { return ((n + m - 1) / m) * m; }
+
+// packed xyz -> padded float4 on the device
+float4* upload_points(Dev& d, const float* xyz, size_t n, int n_pad, float w) {
+  std::vector<float4> h((size_t)n_pad);
+  for (size_t i = 0; i < n; ++i) h[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], w);
+  for (size_t i = n; i < (size_t)n_pad; ++i) h[i] = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, w);
+  float4* p = d.alloc<float4>((size_t)n_pad);
+  if (!p) return nullptr;
+  if (hipMemcpy(p, h.data(), sizeof(float4) * (size_t)n_pad, hipMemcpyHostToDevice) != hipSuccess)
+    return nullptr;
+  return p;
+}
+
+void expand_cov(const std::vector<double>& c6, size_t n, double* cov9) {
+  for (size_t i = 0; i < n; ++i) {
+    const double* c = &c6[6 * i];
+    double* o = cov9 + 9 * i;
+    o[0] = c[0], o[1] = c[1], o[2] = c[2];
+    o[3] = c[1], o[4] = c[3], o[5] = c[4];
+    o[6] = c[2], o[7] = c[4], o[8] = c[5];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lgicp_nn_search(lgicp_ctx* ctx, const float T[16], const float* src_xyz, size_t n_src,
+                    const float* tgt_xyz, size_t n_tgt, int32_t* idx, float* d2, int n_splits) {
+  if (!ctx || !T || (n_src && (!src_xyz || !idx || !d2)) || (n_tgt && !tgt_xyz))
+    return fail(ctx, LGICP_E_INVALID, "null argument");
+  if (n_src > (size_t)1 << 28 || n_tgt > (size_t)1 << 28)
+    return fail(ctx, LGICP_E_INVALID, "cloud too large");
+  if (n_src == 0) return LGICP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t st = ctx->stream;
+  Dev d;
+  const int n_pad_t = std::max(NN_TILE, round_up((int)n_tgt, NN_TILE));
+  const int n_pad_s = std::max(NN_TILE, round_up((int)n_src, NN_TILE));
+  float4* d_src = upload_points(d, src_xyz, n_src, n_pad_s, 1.f);
+  float4* d_tgt = upload_points(d, tgt_xyz, n_tgt, n_pad_t, 1.f);
+  nnkey_t* d_keys = d.alloc<nnkey_t>(n_src);
+  CloudDev* d_clouds = d.alloc<CloudDev>(2);
+  PairDev* d_pair = d.alloc<PairDev>(1);
+  PairState* d_state = d.alloc<PairState>(1);
+  int32_t* d_idx = d.alloc<int32_t>(n_src);
+  float* d_d2 = d.alloc<float>(n_src);
+  if (!d_src || !d_tgt || !d_keys || !d_clouds || !d_pair || !d_state || !d_idx || !d_d2)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  CloudDev hc[2];
+  std::memset(hc, 0, sizeof(hc));
+  hc[0].xyz = d_src, hc[0].n = (int)n_src, hc[0].n_pad = n_pad_s;
+  hc[1].xyz = d_tgt, hc[1].n = (int)n_tgt, hc[1].n_pad = n_pad_t;
+  PairDev hp;
+  std::memset(&hp, 0, sizeof(hp));
+  hp.src_cloud = 0, hp.tgt_cloud = 1, hp.scan1_cloud = 0, hp.scan2_cloud = 1;
+  hp.out = d_src, hp.keys = d_keys, hp.n_src = (int)n_src, hp.n_tgt = (int)n_tgt;
+  PairState hs;
+  std::memset(&hs, 0, sizeof(hs));
+  std::memcpy(hs.T, T, sizeof(hs.T));
+  hs.active = 1;
+  const int QB = nn_queries_per_block(ctx->nn_variant);
+  const int qt = ((int)n_src + QB - 1) / QB, tiles = n_pad_t / NN_TILE;
+  int sp = n_splits;
+  if (sp <= 0) {
+    sp = 1;
+    while ((long long)qt * sp < 1024 && sp < 64) sp *= 2;
+  }
+  sp = std::max(1, std::min(sp, tiles));
+  std::vector<int4> bmap;
+  for (int t = 0; t < qt; ++t)
+    for (int s = 0; s < sp; ++s) bmap.push_back(make_int4(0, t, s, sp));
+  int4* d_bmap = d.alloc<int4>(bmap.size());
+  if (!d_bmap) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, hipMemcpy(d_clouds, hc, sizeof(hc), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_pair, &hp, sizeof(hp), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_bmap, bmap.data(), sizeof(int4) * bmap.size(), hipMemcpyHostToDevice));
+  if (sp > 1) HIP_TRY(ctx, launch_keys_fill(d_pair, d_state, 1, (int)n_src, false, st));
+  HIP_TRY(ctx, launch_nn_search(d_clouds, d_pair, d_state, d_bmap, (int)bmap.size(), false, sp > 1,
+                                ctx->nn_variant, st));
+  HIP_TRY(ctx, launch_keys_unpack(d_keys, (int)n_src, d_idx, d_d2, st));
+  HIP_TRY(ctx, hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * n_src, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d2, d_d2, sizeof(float) * n_src, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return LGICP_OK;
+}
+
+int lgicp_covariances_from_normals(lgicp_ctx* ctx, const float* normals, size_t n, double* cov9) {
+  if (!ctx || (n && (!normals || !cov9))) return fail(ctx, LGICP_E_INVALID, "null argument");
+  if (n == 0) return LGICP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  Dev d;
+  float4* d_n = upload_points(d, normals, n, (int)n, 0.f);
+  double* d_c = d.alloc<double>(6 * n);
+  if (!d_n || !d_c) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, launch_cov_from_normals(d_n, (int)n, d_c, ctx->stream));
+  std::vector<double> h(6 * n);
+  HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_c, sizeof(double) * 6 * n, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  expand_cov(h, n, cov9);
+  return LGICP_OK;
+}
+
+int lgicp_covariances_knn(lgicp_ctx* ctx, const float* xyz, size_t n, int k, double eps,
+                          double* cov9) {
+  if (!ctx || (n && (!xyz || !cov9))) return fail(ctx, LGICP_E_INVALID, "null argument");
+  if (k < 1 || k > 32) return fail(ctx, LGICP_E_INVALID, "k must be in 1..32");
+  if ((size_t)k > n)  // the reference leaves the covariances empty (gicp.hpp:72-79)
+    return fail(ctx, LGICP_E_INVALID, "cloud has fewer points (%zu) than k (%d)", n, k);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  Dev d;
+  const int n_pad = std::max(NN_TILE, round_up((int)n, NN_TILE));
+  float4* d_x = upload_points(d, xyz, n, n_pad, 1.f);
+  double* d_c = d.alloc<double>(6 * n);
+  if (!d_x || !d_c) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, launch_cov_knn(d_x, (int)n, n_pad, k, eps, d_c, ctx->stream));
+  std::vector<double> h(6 * n);
+  HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_c, sizeof(double) * 6 * n, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  expand_cov(h, n, cov9);
+  return LGICP_OK;
+}
+
+int lgicp_compute_ap(lgicp_ctx* ctx, const float* query_xyz, size_t n_query,
+                     const float* ref_normals, size_t n_ref, const int32_t* corr, size_t n_corr,
+                     const float T[16], int normalize_query, double Ap[36]) {
+  if (!ctx || !T || !Ap || (n_query && !query_xyz) || (n_ref && !ref_normals) ||
+      (n_corr && !corr))
+    return fail(ctx, LGICP_E_INVALID, "null argument");
+  for (int i = 0; i < 36; ++i) Ap[i] = 0.0;
+  const size_t n = std::min(n_query, n_corr);
+  if (n == 0) return LGICP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t st = ctx->stream;
+  Dev d;
+  float4* d_q = upload_points(d, query_xyz, n_query, (int)n_query, 1.f);
+  float4* d_n = upload_points(d, ref_normals, n_ref, (int)std::max<size_t>(n_ref, 1), 0.f);
+  std::vector<nnkey_t> hk(n);
+  for (size_t i = 0; i < n; ++i)
+    hk[i] = corr[i] < 0 ? NNKEY_NONE : (nnkey_t)(unsigned)corr[i];
+  nnkey_t* d_keys = d.alloc<nnkey_t>(n);
+  CloudDev* d_clouds = d.alloc<CloudDev>(2);
+  PairDev* d_pair = d.alloc<PairDev>(1);
+  PairState* d_state = d.alloc<PairState>(1);
+  int4* d_bmap = d.alloc<int4>(RED_MAX_CHUNKS);
+  int* d_ids = d.alloc<int>(1);
+  double* d_part = d.alloc<double>((size_t)RED_MAX_CHUNKS * NPOST);
+  if (!d_q || !d_n || !d_keys || !d_clouds || !d_pair || !d_state || !d_bmap || !d_ids || !d_part)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  CloudDev hc[2];
+  std::memset(hc, 0, sizeof(hc));
+  hc[0].xyz = d_q, hc[0].n = (int)n_query, hc[0].n_pad = (int)n_query, hc[0].factor = 1.f;
+  hc[1].nrm = d_n, hc[1].n = (int)n_ref;
+  PairDev hp;
+  std::memset(&hp, 0, sizeof(hp));
+  hp.src_cloud = 0, hp.tgt_cloud = 1, hp.scan1_cloud = 0, hp.scan2_cloud = 1;
+  hp.keys = d_keys, hp.n_src = (int)n;
+  PairState hs;
+  std::memset(&hs, 0, sizeof(hs));
+  std::memcpy(hs.Tfinal, T, sizeof(hs.Tfinal));
+  const int chunks = std::max(1, std::min(RED_MAX_CHUNKS, ((int)n + 4095) / 4096));
+  int4 hb[RED_MAX_CHUNKS];
+  for (int c = 0; c < chunks; ++c) hb[c] = make_int4(0, c, chunks, 0);
+  const int zero = 0;
+  HIP_TRY(ctx, hipMemcpy(d_keys, hk.data(), sizeof(nnkey_t) * n, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_clouds, hc, sizeof(hc), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_pair, &hp, sizeof(hp), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_bmap, hb, sizeof(int4) * chunks, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_ids, &zero, sizeof(int), hipMemcpyHostToDevice));
+  if (normalize_query) HIP_TRY(ctx, launch_normalize_constants(d_clouds, d_ids, 1, st));
+  HIP_TRY(ctx, launch_post_reduce(d_clouds, d_pair, d_state, d_bmap, chunks, d_part, st));
+  std::vector<double> hpart((size_t)chunks * NPOST);
+  HIP_TRY(ctx, hipMemcpyAsync(hpart.data(), d_part, sizeof(double) * hpart.size(),
+                              hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  double post[NPOST] = {0};
+  for (int c = 0; c < chunks; ++c)
+    for (int k = 0; k < NPOST; ++k) post[k] += hpart[(size_t)c * NPOST + k];
+  int k = 3;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) Ap[a * 6 + b] = Ap[b * 6 + a] = post[k++];
+  return LGICP_OK;
+}
+
+}  // extern "C"

@@ -28,7 +28,7 @@ void lo_normalize_cloud(const float* xyz, int n, float* out) {
   float dist = 0.f;
   for (int i = 0; i < n; ++i) {
     const float dx = xyz[3 * i] - c[0], dy = xyz[3 * i + 1] - c[1], dz = xyz[3 * i + 2] - c[2];
-    dist = dist + sqrtf((dx * dx + dy * dy) + dz * dz);
+    dist = dist + sqrtf(dx * dx + (dy * dy + dz * dz)); /* Eigen redux of a Vector3f: x2 + (y2 + z2) */
   }
   const float factor = (float)(size_t)n / dist;
   float T[16] = {0};
