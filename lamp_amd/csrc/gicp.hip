@@ -285,6 +285,19 @@ __device__ void apply_state(const double x[6], float T[16]) {
   T[15] = 1.f;
 }
 
+// FNV-1a over the 16 float words of a transformation
+__device__ unsigned long long hash_T(const float T[16]) {
+  unsigned long long h = 1469598103934665603ull;
+  for (int i = 0; i < 16; ++i) {
+    const unsigned w = __float_as_uint(T[i]);
+    for (int b = 0; b < 4; ++b) {
+      h ^= (w >> (8 * b)) & 0xFFu;
+      h *= 1099511628211ull;
+    }
+  }
+  return h;
+}
+
 __device__ void mat4f_mul(const float a[16], const float b[16], float out[16]) {
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
@@ -419,7 +432,20 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     const int it = S.iterations + 1;
     S.iterations = it;
     for (int i = 0; i < 16; ++i) S.T[i] = T[i];
-    if (it >= sp.max_iterations || delta < 1) {
+    // With tf_epsilon = 1e-10 the test delta < 1 asks for a bit-identical float translation;
+    // the exact minimiser can instead settle into a short limit cycle in which one
+    // correspondence flips and T alternates between float-adjacent matrices (periods 2 and 6
+    // observed).  A transformation already used for the lookups within the last 16 iterations
+    // proves that no further progress is possible: stop as converged (the reference's BFGS
+    // reports NoProgress in the same spot).
+    bool cycle = false;
+    {
+      const unsigned long long h = hash_T(T);
+      const int n_hist = it - 1 < 16 ? it - 1 : 16;
+      for (int k = 0; k < n_hist; ++k) cycle = cycle || (S.Thash[k] == h);
+      S.Thash[(it - 1) % 16] = hash_T(Tprev);
+    }
+    if (it >= sp.max_iterations || delta < 1 || cycle) {
       S.converged = 1;
       for (int i = 0; i < 16; ++i) Tprev[i] = T[i];
       done = true;
@@ -432,6 +458,7 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     mat4f_mul(Tprev, G, Tf);  // final_transformation_ = previous_ * guess (gicp.hpp:583)
     for (int i = 0; i < 16; ++i) S.Tfinal[i] = Tf[i];
     S.active = 0;
+    n_done[1 + pair] = 1;  // per-pair "left the loop" flag, read by the host with the counter
     atomicAdd(n_done, 1);
   }
 }

@@ -131,7 +131,7 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
   if (cfg->reserved[0] == 2 || cfg->reserved[0] == 4 || cfg->reserved[0] == 8)
     ctx->nn_variant = cfg->reserved[0];
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipHostMalloc((void**)&ctx->h_done, sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&ctx->h_done, sizeof(int) * 65536, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
     return fail(nullptr, LGICP_E_HIP, "stream / pinned allocation failed");
   }
@@ -379,47 +379,60 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   }
 
   // ---- block maps ----------------------------------------------------------------------------
+  // Rebuilt whenever pairs drop out of the outer loop: the 1-NN grid covers the active pairs
+  // only, and when few are left their targets are split over several workgroups so that the
+  // launch still offers >= ~4 workgroups per CU.
   const int QB = nn_queries_per_block(ctx->nn_variant);
-  long long base_blocks = 0;
-  for (auto& pd : h_pairs) base_blocks += (pd.n_src + QB - 1) / QB;
-  int splits = 1;
-  {
-    const int forced = cfg.reserved[1];
-    if (forced > 0)
-      splits = forced;
-    else
-      while (base_blocks * splits < 1024 && splits < 64) splits *= 2;
-  }
   std::vector<int4> h_bmap_nn, h_bmap_red;
   std::vector<int> h_ints((size_t)2 * n_pairs + 4, 0);
-  double evals_per_pass = 0;
   bool any_split = false;
+  auto build_maps = [&](const std::vector<int>& act) {
+    long long base_blocks = 0;
+    for (int p : act) base_blocks += (h_pairs[p].n_src + QB - 1) / QB;
+    int splits = 1;
+    if (cfg.reserved[1] > 0)
+      splits = cfg.reserved[1];
+    else
+      while (base_blocks * splits < 1024 && splits < 64) splits *= 2;
+    h_bmap_nn.clear();
+    h_bmap_red.clear();
+    any_split = false;
+    for (int p : act) {
+      const PairDev& pd = h_pairs[p];
+      const int tiles = bp.clouds[bp.pairs[p].tgt_cloud].n_pad / NN_TILE;
+      const int sp = std::max(1, std::min(splits, tiles));
+      any_split |= sp > 1;
+      const int qt = (pd.n_src + QB - 1) / QB;
+      for (int t = 0; t < qt; ++t)
+        for (int s = 0; s < sp; ++s) h_bmap_nn.push_back(make_int4(p, t, s, sp));
+      for (int c = 0; c < h_ints[p]; ++c) h_bmap_red.push_back(make_int4(p, c, h_ints[p], 0));
+    }
+    xcd_permute(h_bmap_nn);
+  };
+  std::vector<int> all_pairs((size_t)n_pairs);
+  size_t max_nn_blocks = 0;
+  double evals_per_pass = 0;
   for (int p = 0; p < n_pairs; ++p) {
+    all_pairs[p] = p;
     const PairDev& pd = h_pairs[p];
+    h_ints[p] = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + 4095) / 4096));
     const int tiles = bp.clouds[bp.pairs[p].tgt_cloud].n_pad / NN_TILE;
-    const int sp = std::max(1, std::min(splits, tiles));
-    any_split |= sp > 1;
-    const int qt = (pd.n_src + QB - 1) / QB;
-    for (int t = 0; t < qt; ++t)
-      for (int s = 0; s < sp; ++s) h_bmap_nn.push_back(make_int4(p, t, s, sp));
-    int chunks = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + 4095) / 4096));
-    h_ints[p] = chunks;
-    for (int c = 0; c < chunks; ++c) h_bmap_red.push_back(make_int4(p, c, chunks, 0));
+    max_nn_blocks += (size_t)((pd.n_src + QB - 1) / QB) * (size_t)std::min(64, tiles);
     evals_per_pass += (double)pd.n_src * (double)pd.n_tgt;
   }
-  xcd_permute(h_bmap_nn);
+  build_maps(all_pairs);
   std::vector<int> scan1_ids;
   for (int c = 0; c < n_clouds; ++c)
     if (bp.clouds[c].need_norm_constants) scan1_ids.push_back(c);
   for (size_t i = 0; i < scan1_ids.size(); ++i) h_ints.push_back(scan1_ids[i]);
   const size_t off_ids = (size_t)2 * n_pairs + 4;
-  const size_t off_done = (size_t)n_pairs;  // n_done lives right after n_chunks
+  const size_t off_done = (size_t)n_pairs;  // n_done, then one "active" flag per pair
 
   HIP_TRY(ctx, ctx->d_clouds.reserve(n_clouds));
   HIP_TRY(ctx, ctx->d_pairs.reserve(n_pairs));
   HIP_TRY(ctx, ctx->d_state.reserve(n_pairs));
   HIP_TRY(ctx, ctx->d_segs.reserve(std::max<size_t>(h_segs.size(), 1)));
-  HIP_TRY(ctx, ctx->d_bmap_nn.reserve(h_bmap_nn.size()));
+  HIP_TRY(ctx, ctx->d_bmap_nn.reserve(std::max(max_nn_blocks, h_bmap_nn.size())));
   HIP_TRY(ctx, ctx->d_bmap_red.reserve(h_bmap_red.size()));
   HIP_TRY(ctx, ctx->d_ints.reserve(h_ints.size()));
   HIP_TRY(ctx, ctx->d_partials.reserve((size_t)n_pairs * RED_MAX_CHUNKS * NSTAT));
@@ -474,12 +487,22 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   sp.max_iterations = cfg.iterations;
   sp.max_inner_iterations = cfg.optimizer_iterations;
   int* d_done = ctx->d_ints.p + off_done;
-  int n_inactive0 = 0;
-  for (auto& s : h_state) n_inactive0 += s.active ? 0 : 1;
+  std::vector<int> active;
+  for (int p = 0; p < n_pairs; ++p)
+    if (h_state[p].active) active.push_back(p);
+  const int n_inactive0 = n_pairs - (int)active.size();
+  if (n_inactive0) {
+    build_maps(active);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, h_bmap_nn.data(),
+                                sizeof(int4) * h_bmap_nn.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
+                                sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_ev, red_ev, sol_ev;
-  int outer = 0;
-  ctx->h_done[0] = 0;
-  while (n_inactive0 + ctx->h_done[0] < n_pairs && outer < cfg.iterations + 1) {
+  std::vector<int> h_flags((size_t)n_pairs + 1, 0);
+  int outer = 0, done_seen = 0;
+  while (!active.empty() && outer < cfg.iterations + 1) {
     hipEvent_t a = ctx->event(), b = ctx->event(), c = ctx->event(), d = ctx->event();
     HIP_TRY(ctx, hipEventRecord(a, st));
     if (any_split)
@@ -495,15 +518,36 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
     HIP_TRY(ctx, launch_gicp_solve(ctx->d_pairs.p, ctx->d_state.p, n_pairs, ctx->d_ints.p,
                                    ctx->d_partials.p, sp, d_done, st));
     HIP_TRY(ctx, hipEventRecord(d, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_done, d_done, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_done, d_done, sizeof(int) * ((size_t)n_pairs + 1),
+                                hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     nn_ev.emplace_back(a, b);
     red_ev.emplace_back(b, c);
     sol_ev.emplace_back(c, d);
     ++outer;
+    if (ctx->h_done[0] != done_seen) {
+      done_seen = ctx->h_done[0];
+      active.clear();
+      for (int p = 0; p < n_pairs; ++p)
+        if (h_state[p].active && !ctx->h_done[1 + p]) active.push_back(p);
+      if (!active.empty()) {
+        build_maps(active);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, h_bmap_nn.data(),
+                                    sizeof(int4) * h_bmap_nn.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
+                                    sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+      }
+    }
   }
 
   // ---- final pass: fitness + correspondences + Ap ----------------------------------------------
+  build_maps(all_pairs);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size(),
+                              hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
+                              sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
   hipEvent_t ev_post0 = ctx->event(), ev_post1 = ctx->event(), ev_post2 = ctx->event();
   HIP_TRY(ctx, hipEventRecord(ev_post0, st));
   if (any_split)
@@ -664,7 +708,9 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
         continue;
       }
       const size_t est = (size_t)ctx->scans.at(c.key_from).n * 24 * (cfg.accumulate_source ? 5 : 1);
-      if (!bp.pairs.empty() && bp.bytes + pair_bytes + est > cfg.workspace_bytes) break;
+      if (!bp.pairs.empty() &&
+          (bp.bytes + pair_bytes + est > cfg.workspace_bytes || bp.pairs.size() >= 32768))
+        break;
       PairPlan pp;
       pp.cand = i;
       pp.tgt_cloud = plan_cloud(ctx, bp, c.key_to, true);

@@ -56,6 +56,7 @@ struct PairState {
   float T[16];       // transformation_
   float Tprev[16];   // previous_transformation_
   float Tfinal[16];  // previous_ * guess
+  unsigned long long Thash[16];  // hashes of the lookup transformations of the last iterations
   double delta;
   int iterations;
   int converged;

@@ -872,6 +872,21 @@ static int estimate_gn(lo_functor* F, int max_inner, float T[16]) {
 
 /* ------------------------------------------------------------------ computeTransformation */
 
+#define LO_CYCLE_HISTORY 16
+/* FNV-1a over the 16 float words of a transformation */
+static uint64_t hash_T(const float T[16]) {
+  uint64_t h = 1469598103934665603ull;
+  for (int i = 0; i < 16; ++i) {
+    uint32_t w;
+    memcpy(&w, &T[i], 4);
+    for (int b = 0; b < 4; ++b) {
+      h ^= (w >> (8 * b)) & 0xFFu;
+      h *= 1099511628211ull;
+    }
+  }
+  return h;
+}
+
 void lo_gicp_default_params(lo_gicp_params* p) {
   p->corr_dist = 5.0;              /* gicp.h:135 */
   p->tf_epsilon = 5e-4;            /* gicp.h:134 */
@@ -925,6 +940,8 @@ int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* sr
   const double dist_threshold = p->corr_dist * p->corr_dist;
   int converged = 0, nr_iterations = 0;
   double delta = 0.;
+  uint64_t hist[LO_CYCLE_HISTORY]; /* hashes of earlier lookup transformations (GN cycle exit) */
+  memset(hist, 0, sizeof(hist));
   if (!cov_ok) {
     /* the reference would index an empty covariance vector here (undefined behaviour);
      * the oracle reports a failed, unconverged alignment instead */
@@ -987,7 +1004,22 @@ int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* sr
         if (c_delta > delta) delta = c_delta;
       }
     nr_iterations++;
-    if (nr_iterations >= p->max_iterations || delta < 1) {
+    /* Gauss-Newton back end only (not in the reference): with tf_epsilon = 1e-10 the test
+     * delta < 1 asks for a bit-identical float translation, and the exact minimiser can settle
+     * into a short limit cycle in which one correspondence flips and T alternates between
+     * float-adjacent matrices (periods 2 and 6 have been observed).  A transformation that was
+     * already used for the lookups within the last LO_CYCLE_HISTORY iterations proves that no
+     * further progress is possible: stop as converged. */
+    int cycle = 0;
+    if (p->solver == LO_SOLVER_GN) {
+      const uint64_t h = hash_T(T);
+      const int n_hist = nr_iterations - 1 < LO_CYCLE_HISTORY ? nr_iterations - 1 : LO_CYCLE_HISTORY;
+      for (int k = 0; k < n_hist; ++k)
+        if (hist[k] == h) cycle = 1;
+      /* ring of the transformations used for the lookups of the last iterations */
+      hist[(nr_iterations - 1) % LO_CYCLE_HISTORY] = hash_T(Tprev);
+    }
+    if (nr_iterations >= p->max_iterations || delta < 1 || cycle) {
       converged = 1;
       memcpy(Tprev, T, sizeof(T));
     }
