@@ -21,22 +21,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32 peak (packed FMA), per GPU
-RESULT_WIDTH = 128              # doubles per gathered pair record
-
-
-def pack_results(results):
-    out = np.zeros((len(results), RESULT_WIDTH), np.float64)
-    for i, r in enumerate(results):
-        row = out[i]
-        row[0], row[1], row[2], row[3] = r.key_from, r.key_to, r.status, r.iterations
-        row[4] = r.fitness
-        row[5:21] = r.T_icp[:]
-        row[21:30] = r.delta_R[:]
-        row[30:33] = r.delta_t[:]
-        row[33:69] = r.covariance[:]
-        row[69:105] = r.information[:]
-    return out
-
 
 def cpu_baseline(work, n_sample, threads):
     """The CPU oracle (kd-tree lookups, BFGS: the reference's configuration) on the first
@@ -89,6 +73,7 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     from lamp_amd import capi
+    from lamp_amd.sharding import gather_records, pack_results
     from lamp_amd.workload import Workload
 
     work = Workload(args.config, pairs=args.pairs, points=args.points, keyframes=args.keyframes,
@@ -110,9 +95,7 @@ def main():
         res = ctx.submit(cands)             # blocking: returns after the device work is done
         if dist is not None:
             import torch
-            rec = torch.from_numpy(pack_results(res)).cuda()
-            gathered = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
-            dist.gather(rec, gathered, dst=0)
+            gather_records(pack_results(res), dist, rank, world, torch.device("cuda", local_rank))
             torch.cuda.synchronize()
         return res
 

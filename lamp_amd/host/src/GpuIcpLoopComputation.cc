@@ -1,0 +1,223 @@
+// GpuIcpLoopComputation — the reference's IcpLoopComputation driver logic
+// (loop_closure/src/IcpLoopComputation.cc) on top of the lgicp C ABI.
+#include "loop_closure/GpuIcpLoopComputation.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace lamp_loop_closure {
+
+GpuIcpLoopComputation::GpuIcpLoopComputation() { lgicp_default_config(&cfg_, 1); }
+
+GpuIcpLoopComputation::~GpuIcpLoopComputation() {
+  if (ctx_) lgicp_destroy(ctx_);
+}
+
+const char* GpuIcpLoopComputation::last_error() const { return lgicp_last_error(ctx_); }
+
+// IcpLoopComputation::Initialize (IcpLoopComputation.cc:29-56); the thread pool of the
+// reference is replaced by the device batch, so there is nothing to size here
+bool GpuIcpLoopComputation::Initialize(const NodeHandle& n) {
+  if (!LoadParameters(n)) {
+    std::fprintf(stderr, "GpuIcpLoopComputation: Failed to load parameters.\n");
+    return false;
+  }
+  if (!RegisterCallbacks(n)) return false;
+  if (!CreatePublishers(n)) return false;
+  if (ctx_) {
+    lgicp_destroy(ctx_);
+    ctx_ = nullptr;
+    keyed_scans_.clear();
+    closed_keyes_.clear();
+  }
+  if (lgicp_create(&cfg_, &ctx_) != LGICP_OK) {
+    std::fprintf(stderr, "GpuIcpLoopComputation: %s\n", lgicp_last_error(nullptr));
+    return false;
+  }
+  return true;
+}
+
+// IcpLoopComputation::LoadParameters (IcpLoopComputation.cc:58-167): every key is required
+bool GpuIcpLoopComputation::LoadParameters(const NodeHandle& n) {
+  if (!LoopComputation::LoadParameters(n)) return false;
+  const ParameterServer& pu = *n.params;
+  const std::string ns = param_ns_;
+  const int device = cfg_.device;
+  lgicp_default_config(&cfg_, ns == "base");
+  cfg_.device = device;
+  if (!pu.Get(ns + "/keyed_scans_max_delay", keyed_scans_max_delay_)) return false;
+  if (!pu.Get(ns + "/max_tolerable_fitness", cfg_.max_tolerable_fitness)) return false;
+  if (!pu.GetAs(ns + "/distance_before_reclosing", dist_before_reclosing_)) return false;
+  if (!pu.Get(ns + "/icp_lc/tf_epsilon", cfg_.tf_epsilon)) return false;
+  if (!pu.Get(ns + "/icp_lc/corr_dist", cfg_.corr_dist)) return false;
+  if (!pu.GetAs(ns + "/icp_lc/iterations", cfg_.iterations)) return false;
+  int icp_threads;  // OpenMP threads of the reference: no meaning on the device
+  if (!pu.GetAs(ns + "/icp_lc/threads", icp_threads)) return false;
+  if (!pu.GetAs(ns + "/icp_lc/transform_thresholding", cfg_.transform_thresholding)) return false;
+  if (!pu.Get(ns + "/icp_lc/max_translation", cfg_.max_translation)) return false;
+  if (!pu.Get(ns + "/icp_lc/max_rotation", cfg_.max_rotation_deg)) return false;
+  if (!pu.GetAs(ns + "/sac_ia/iterations", cfg_.sac_iterations)) return false;
+  if (!pu.GetAs(ns + "/sac_ia/num_prev_scans", cfg_.num_prev_scans)) return false;
+  if (!pu.GetAs(ns + "/sac_ia/num_next_scans", cfg_.num_next_scans)) return false;
+  if (!pu.GetAs(ns + "/sac_ia/b_accumulate_source", cfg_.accumulate_source)) return false;
+  if (!pu.Get(ns + "/sac_ia/features_radius", cfg_.sac_features_radius)) return false;
+  if (!pu.Get(ns + "/sac_ia/fitness_score_threshold", cfg_.sac_fitness_score_threshold))
+    return false;
+  if (!pu.Get(ns + "/harris3D/harris_threshold", cfg_.harris_threshold)) return false;
+  if (!pu.GetAs(ns + "/harris3D/harris_suppression", cfg_.harris_suppression)) return false;
+  if (!pu.Get(ns + "/harris3D/harris_radius", cfg_.harris_radius)) return false;
+  if (!pu.GetAs(ns + "/harris3D/harris_refine", cfg_.harris_refine)) return false;
+  if (!pu.GetAs(ns + "/harris3D/harris_response", cfg_.harris_response)) return false;
+  if (!pu.GetAs(ns + "/icp_initialization_method", cfg_.init_method)) return false;
+  if (!pu.GetAs(ns + "/icp_covariance_calculation", cfg_.covariance_method)) return false;
+  if (!pu.Get("laser_lc_rot_sigma", cfg_.laser_lc_rot_sigma)) return false;
+  if (!pu.Get("laser_lc_trans_sigma", cfg_.laser_lc_trans_sigma)) return false;
+  if (!pu.GetAs("b_use_fixed_covariances", cfg_.use_fixed_covariances)) return false;
+  double pool;  // host thread pool size of the reference: replaced by the device batch
+  if (!pu.Get(ns + "/icp_thread_pool_thread_count", pool)) return false;
+  return true;
+}
+
+bool GpuIcpLoopComputation::CreatePublishers(const NodeHandle& n) {
+  return LoopComputation::CreatePublishers(n);
+}
+bool GpuIcpLoopComputation::RegisterCallbacks(const NodeHandle& n) {
+  return LoopComputation::RegisterCallbacks(n);
+}
+
+// IcpLoopComputation::KeyedScanCallback (IcpLoopComputation.cc:377-392): first scan wins
+void GpuIcpLoopComputation::KeyedScanCallback(const pose_graph_msgs::KeyedScan& m) {
+  if (keyed_scans_.count(m.key)) return;
+  const pose_graph_msgs::PointXYZINormal* p = m.scan.data();
+  const float* xyz = p ? &p->x : nullptr;
+  const float* nrm = p ? &p->normal_x : nullptr;
+  if (lgicp_add_keyframe(ctx_, m.key, xyz, nrm, m.scan.size(),
+                         sizeof(pose_graph_msgs::PointXYZINormal)) >= 0)
+    keyed_scans_.insert(m.key);
+}
+
+// IcpLoopComputation::KeyedPoseCallback (IcpLoopComputation.cc:394-418): first pose wins
+void GpuIcpLoopComputation::KeyedPoseCallback(const pose_graph_msgs::PoseGraph& g) {
+  for (const auto& node : g.nodes) {
+    const double q[4] = {node.pose.orientation.w, node.pose.orientation.x,
+                         node.pose.orientation.y, node.pose.orientation.z};
+    const double t[3] = {node.pose.position.x, node.pose.position.y, node.pose.position.z};
+    lgicp_add_pose(ctx_, node.key, q, t);
+  }
+}
+
+// IcpLoopComputation::CheckReclosingDistance (IcpLoopComputation.cc:205-240): a pair is
+// skipped when both of its keys lie within dist_before_reclosing_ of an already closed key.
+// The reference dereferences std::prev(begin()) when the key precedes every closed key; the
+// nearest closed key is taken here without that out-of-range read.
+bool GpuIcpLoopComputation::CheckReclosingDistance(uint64_t key_from, uint64_t key_to) const {
+  if (closed_keyes_.empty()) return true;
+  auto nearest = [&](uint64_t key) {
+    auto it = closed_keyes_.lower_bound(key);
+    if (it == closed_keyes_.begin()) return *it;
+    auto prev = std::prev(it);
+    if (it == closed_keyes_.end() || key - *prev <= *it - key) return *prev;
+    return *it;
+  };
+  const uint64_t closest_from = nearest(key_from), closest_to = nearest(key_to);
+  const int df = std::abs(static_cast<int>(closest_from) - static_cast<int>(key_from));
+  const int dt = std::abs(static_cast<int>(closest_to) - static_cast<int>(key_to));
+  return !(df < static_cast<int>(dist_before_reclosing_) &&
+           dt < static_cast<int>(dist_before_reclosing_));
+}
+
+static void fill_candidate(const pose_graph_msgs::LoopCandidate& c, lgicp_candidate* o) {
+  o->key_from = c.key_from;
+  o->key_to = c.key_to;
+  const geometry_msgs::Pose* ps[2] = {&c.pose_from, &c.pose_to};
+  double* qs[2] = {o->pose_from_q, o->pose_to_q};
+  double* ts[2] = {o->pose_from_t, o->pose_to_t};
+  for (int k = 0; k < 2; ++k) {
+    qs[k][0] = ps[k]->orientation.w;
+    qs[k][1] = ps[k]->orientation.x;
+    qs[k][2] = ps[k]->orientation.y;
+    qs[k][3] = ps[k]->orientation.z;
+    ts[k][0] = ps[k]->position.x;
+    ts[k][1] = ps[k]->position.y;
+    ts[k][2] = ps[k]->position.z;
+  }
+}
+
+// IcpLoopComputation::ComputeTransforms (IcpLoopComputation.cc:243-367).  Candidates whose
+// scans have not arrived are re-queued while younger than keyed_scans_max_delay_; the rest
+// go to the device as one batch.  The reclosing filter is order dependent (closed_keyes_ grows
+// as edges are accepted), so it is applied on the host in queue order after the batch
+// returns — the semantics of the reference's serial path (:274-297); its threaded path reads
+// and writes closed_keyes_ concurrently without a lock.
+void GpuIcpLoopComputation::ComputeTransforms() {
+  const size_t n = input_queue_.size();
+  std::vector<pose_graph_msgs::LoopCandidate> batch;
+  for (size_t i = 0; i < n; i++) {
+    auto candidate = input_queue_.front();
+    input_queue_.pop();
+    if (!keyed_scans_.count(candidate.key_from) || !keyed_scans_.count(candidate.key_to)) {
+      if (now_() - candidate.header.stamp < keyed_scans_max_delay_) input_queue_.push(candidate);
+      continue;
+    }
+    batch.push_back(candidate);
+  }
+  if (batch.empty()) return;
+  std::vector<lgicp_candidate> cands(batch.size());
+  std::vector<lgicp_result> results(batch.size());
+  for (size_t i = 0; i < batch.size(); ++i) fill_candidate(batch[i], &cands[i]);
+  if (lgicp_submit(ctx_, cands.data(), cands.size(), results.data()) != LGICP_OK) {
+    std::fprintf(stderr, "GpuIcpLoopComputation: %s\n", lgicp_last_error(ctx_));
+    return;
+  }
+  for (size_t i = 0; i < batch.size(); ++i) {
+    const lgicp_result& r = results[i];
+    if (!CheckReclosingDistance(r.key_from, r.key_to)) continue;
+    if (r.status != LGICP_PAIR_OK) continue;
+    Transform3 transform;
+    std::memcpy(transform.translation, r.delta_t, sizeof(transform.translation));
+    std::memcpy(transform.rotation, r.delta_R, sizeof(transform.rotation));
+    pose_graph_msgs::PoseGraphEdge loop_closure =
+        CreateLoopClosureEdge(r.key_from, r.key_to, transform, r.covariance);
+    closed_keyes_.insert(r.key_from);
+    closed_keyes_.insert(r.key_to);
+    loop_closure.range_error = r.fitness;
+    output_queue_.push_back(loop_closure);
+  }
+}
+
+void GpuIcpLoopComputation::ProcessTimerCallback() {
+  ComputeTransforms();
+  if (loop_closure_pub_) PublishLoopClosures();
+}
+
+// IcpLoopComputation::PerformAlignment for a single pair (what the reference's tests call
+// through their friend fixtures)
+bool GpuIcpLoopComputation::PerformAlignment(uint64_t key1, uint64_t key2,
+                                             const geometry_msgs::Pose& pose1,
+                                             const geometry_msgs::Pose& pose2, Transform3* delta,
+                                             double covariance[36], double* fitness_score) {
+  if (delta == nullptr || covariance == nullptr) return false;
+  pose_graph_msgs::LoopCandidate c;
+  c.key_from = key1;
+  c.key_to = key2;
+  c.pose_from = pose1;
+  c.pose_to = pose2;
+  lgicp_candidate lc;
+  lgicp_result r;
+  fill_candidate(c, &lc);
+  if (lgicp_submit(ctx_, &lc, 1, &r) != LGICP_OK) return false;
+  // delta is filled before the gates in the reference (:568-577): give the ICP transform
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) delta->rotation[a * 3 + b] = r.T_icp[a * 4 + b];
+    delta->translation[a] = r.T_icp[a * 4 + 3];
+  }
+  if (r.status != LGICP_PAIR_OK) return false;
+  std::memcpy(delta->translation, r.delta_t, sizeof(delta->translation));
+  std::memcpy(delta->rotation, r.delta_R, sizeof(delta->rotation));
+  std::memcpy(covariance, r.covariance, sizeof(double) * 36);
+  if (fitness_score) *fitness_score = r.fitness;
+  return true;
+}
+
+}  // namespace lamp_loop_closure

@@ -1,0 +1,200 @@
+// Drives GpuIcpLoopComputation the way the reference's gtest fixtures drive IcpLoopComputation
+// (loop_closure/test/test_loop_computation.cc:125-182, test_icp_computation.cpp:53-162):
+// hand-built messages pushed through the callbacks.  Prints one JSON object; exit code 0 = all
+// checks passed.  `--host-only` runs the checks that need no GPU.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "loop_closure/GpuIcpLoopComputation.h"
+
+using namespace lamp_loop_closure;
+using pose_graph_msgs::PointCloud;
+using pose_graph_msgs::PointXYZINormal;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                      \
+  do {                                                                   \
+    if (!(cond)) {                                                       \
+      std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      ++g_fail;                                                          \
+    }                                                                    \
+  } while (0)
+
+// 10x10 plane, 0.1 m pitch, normal +z; corner = planes z=0, y=0 (n=-y), x=0 (n=-x)
+static PointCloud Plane() {
+  PointCloud pc;
+  for (size_t ix = 0; ix < 10; ix++)
+    for (size_t iy = 0; iy < 10; iy++) {
+      PointXYZINormal p;
+      p.x = ix * 0.1f, p.y = iy * 0.1f, p.z = 0.f, p.normal_z = 1.f;
+      pc.push_back(p);
+    }
+  return pc;
+}
+static PointCloud Corner() {
+  PointCloud plane = Plane(), out = plane;
+  for (const auto& p : plane) {
+    PointXYZINormal q;
+    q.x = p.x, q.y = -p.z, q.z = p.y, q.normal_x = p.normal_x, q.normal_y = -p.normal_z,
+    q.normal_z = p.normal_y;
+    out.push_back(q);
+  }
+  for (const auto& p : plane) {
+    PointXYZINormal q;
+    q.x = -p.z, q.y = p.y, q.z = p.x, q.normal_x = -p.normal_z, q.normal_y = p.normal_y,
+    q.normal_z = p.normal_x;
+    out.push_back(q);
+  }
+  return out;
+}
+static PointCloud Shift(const PointCloud& in, float dx, float dy) {
+  PointCloud out = in;
+  for (auto& p : out) p.x = p.x + dx, p.y = p.y + dy;
+  return out;
+}
+
+struct Probe : GpuIcpLoopComputation {
+  size_t input_size() const { return input_queue_.size(); }
+  void close(uint64_t k) { closed_keyes_.insert(k); }
+  void set_reclosing(unsigned d) { dist_before_reclosing_ = d; }
+};
+
+static void HostOnly() {
+  Probe icp;
+  ParameterServer ps = ParameterServer::ReferenceDefaults();
+  NodeHandle nh{"base", &ps};
+  CHECK(icp.LoadParameters(nh));
+  CHECK(icp.config().iterations == 200 && icp.config().corr_dist == 0.5);
+  CHECK(icp.config().init_method == LGICP_INIT_FEATURES);
+  ParameterServer missing;
+  NodeHandle bad{"base", &missing};
+  Probe icp2;
+  CHECK(!icp2.LoadParameters(bad));  // pu::Get failure -> false, as in the reference
+  // reclosing filter
+  icp.set_reclosing(5);
+  CHECK(icp.CheckReclosingDistance(10, 200));
+  icp.close(10);
+  icp.close(200);
+  CHECK(!icp.CheckReclosingDistance(12, 203));
+  CHECK(icp.CheckReclosingDistance(12, 300));
+  CHECK(icp.CheckReclosingDistance(1, 203));           // 1 is 9 keys away from 10
+  CHECK(!icp.CheckReclosingDistance(8, 203));          // key below every closed key
+  CHECK(icp.CheckReclosingDistance(100, 100));
+  // edge message
+  Transform3 tf;
+  tf.translation[0] = 1, tf.translation[1] = -0.001;
+  double cov[36];
+  for (int i = 0; i < 36; ++i) cov[i] = i;
+  auto e = icp.CreateLoopClosureEdge(7, 9, tf, cov);
+  CHECK(e.key_from == 7 && e.key_to == 9 && e.type == pose_graph_msgs::PoseGraphEdge::LOOPCLOSE);
+  CHECK(e.pose.orientation.w == 1.0 && e.pose.position.x == 1.0 && e.covariance[35] == 35);
+  // queue
+  pose_graph_msgs::LoopCandidateArray arr;
+  arr.candidates.resize(3);
+  icp.InputCallback(arr);
+  CHECK(icp.input_size() == 3);
+  int status_count = 0;
+  icp.status_pub_ = [&](const pose_graph_msgs::LoopComputationStatus& s) {
+    status_count += s.type == pose_graph_msgs::LoopComputationStatus::COMPLETED_ALL;
+  };
+  icp.PublishLoopClosures();
+  CHECK(status_count == 1);
+}
+
+static void OnDevice() {
+  ParameterServer ps = ParameterServer::ReferenceDefaults();
+  ps.Set("base/icp_initialization_method", LGICP_INIT_ODOMETRY);
+  NodeHandle nh{"base", &ps};
+  {  // TestLoopComputation.PerformAlignment
+    Probe icp;
+    CHECK(icp.Initialize(nh));
+    PointCloud corner = Corner(), moved = Shift(corner, 1.f, -0.001f);
+    icp.KeyedScanCallback({0, corner});
+    icp.KeyedScanCallback({100, moved});
+    icp.KeyedScanCallback({100, corner});  // ignored: first wins
+    pose_graph_msgs::PoseGraph kp;
+    pose_graph_msgs::PoseGraphNode kp0, kp100;
+    kp0.key = 0, kp100.key = 100;
+    kp0.pose.position.z = 0.1;
+    kp100.pose.position.x = -0.9, kp100.pose.position.y = 0.1;
+    kp.nodes = {kp0, kp100};
+    icp.KeyedPoseCallback(kp);
+    Transform3 tf;
+    double cov[36], fit = -1;
+    CHECK(icp.PerformAlignment(100, 0, kp100.pose, kp0.pose, &tf, cov, &fit));
+    CHECK(std::fabs(tf.translation[0] - 1) < 1e-3 && std::fabs(tf.translation[1] + 0.001) < 1e-3 &&
+          std::fabs(tf.translation[2]) < 1e-3);
+    for (int i = 0; i < 9; ++i) CHECK(std::fabs(tf.rotation[i] - (i % 4 == 0 ? 1 : 0)) < 1e-3);
+    CHECK(fit >= 0 && fit < 1e-6);
+    std::printf("{\"perform_alignment_t\": [%.6f, %.6f, %.6f], \"fitness\": %.3g, ",
+                tf.translation[0], tf.translation[1], tf.translation[2], fit);
+  }
+  {  // TestICPComputation.TestThreadedEqualsNonThreaded, device batch instead of the pool
+    ps.Set("base/icp_lc/iterations", 100);
+    Probe icp;
+    CHECK(icp.Initialize(nh));
+    const size_t test_size = 100;
+    PointCloud base = Corner();
+    pose_graph_msgs::PoseGraph graph;
+    for (uint64_t k = 0; k < test_size * 2; ++k) {
+      // keys 10 apart: accumulation of +-2 neighbours must not merge them
+      icp.KeyedScanCallback({10 * k, Shift(base, (k % 2) == 1 ? -1.0f : 1.0f, 0.f)});
+      pose_graph_msgs::PoseGraphNode node;
+      node.key = 10 * k;
+      node.pose.position.x = (k % 2) == 1 ? 1.0 : -1.0;
+      graph.nodes.push_back(node);
+    }
+    icp.KeyedPoseCallback(graph);
+    pose_graph_msgs::LoopCandidateArray cands;
+    for (uint64_t k = 0; k < test_size; ++k) {
+      pose_graph_msgs::LoopCandidate c;
+      c.key_to = 10 * k;
+      c.key_from = 10 * (k + test_size);
+      cands.candidates.push_back(c);
+    }
+    // a candidate whose scan never arrives: re-queued while young, dropped when old
+    pose_graph_msgs::LoopCandidate late;
+    late.key_from = 999999, late.key_to = 0, late.header.stamp = 0;
+    cands.candidates.push_back(late);
+    icp.InputCallback(cands);
+    icp.set_reclosing(0);  // every pair is its own place in this fixture
+    double now = 1.0;
+    icp.now_ = [&] { return now; };
+    icp.ComputeTransforms();
+    auto out = icp.GetCurrentOutputQueue();
+    CHECK(out.size() == test_size);
+    CHECK(icp.input_size() == 1);  // the late candidate waits
+    now = 1e6;
+    icp.ComputeTransforms();
+    CHECK(icp.input_size() == 0);  // ...and is dropped after keyed_scans_max_delay
+    size_t sign_ok = 0;
+    for (const auto& e : out) {
+      const uint64_t k = e.key_to / 10;
+      // source and target alternate between x=+1 and x=-1 with the key parity
+      const double expect = ((k % 2) == 1 ? -1.0 : 1.0) - (((k + test_size) % 2) == 1 ? -1.0 : 1.0);
+      sign_ok += std::fabs(e.pose.position.x + expect) < 1e-3 || std::fabs(e.pose.position.x - expect) < 1e-3;
+    }
+    CHECK(sign_ok == out.size());
+    int published = 0, completed = 0;
+    icp.loop_closure_pub_ = [&](const pose_graph_msgs::PoseGraph& g) { published += (int)g.edges.size(); };
+    icp.status_pub_ = [&](const pose_graph_msgs::LoopComputationStatus&) { ++completed; };
+    icp.PublishLoopClosures();
+    CHECK(published == (int)test_size && completed == 1);
+    CHECK(icp.GetCurrentOutputQueue().empty());
+    std::printf("\"batch_edges\": %zu}\n", out.size());
+  }
+}
+
+int main(int argc, char** argv) {
+  const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
+  HostOnly();
+  if (!host_only) OnDevice();
+  if (g_fail) {
+    std::fprintf(stderr, "%d check(s) failed\n", g_fail);
+    return 1;
+  }
+  if (host_only) std::printf("{\"host_only\": true}\n");
+  return 0;
+}

@@ -1,0 +1,75 @@
+"""Multi-GPU sharding of candidate pairs (one process per GPU) and the result gather.
+
+Candidate pairs are independent (the reference already treats them so with its thread pool,
+loop_closure/src/IcpLoopComputation.cc:327-356), so the data path needs no collective: every
+rank aligns its own pairs on its own GPU.  The only exchange is the gather of fixed-size result
+records to rank 0, done with torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).
+"""
+import numpy as np
+
+RESULT_WIDTH = 128  # doubles per pair record
+
+
+def partition_pairs(pairs, cloud_sizes, world):
+    """Greedy longest-processing-time assignment of pairs to ranks by estimated cost
+    n_src * n_tgt, with an affinity bonus for ranks that already hold one of the pair's
+    keyframes (each keyframe is uploaded once per GPU that needs it).  Deterministic.
+    Returns a list of index lists, one per rank."""
+    cost = [float(cloud_sizes[a]) * float(cloud_sizes[b]) for a, b in pairs]
+    order = sorted(range(len(pairs)), key=lambda i: (-cost[i], i))
+    load = [0.0] * world
+    held = [set() for _ in range(world)]
+    out = [[] for _ in range(world)]
+    mean = (sum(cost) / max(len(cost), 1)) or 1.0
+    for i in order:
+        a, b = pairs[i]
+        best, best_score = 0, None
+        for r in range(world):
+            shared = (a in held[r]) + (b in held[r])
+            score = load[r] - 0.25 * mean * shared
+            if best_score is None or score < best_score:
+                best, best_score = r, score
+        out[best].append(i)
+        load[best] += cost[i]
+        held[best].update((a, b))
+    for r in range(world):
+        out[r].sort()
+    return out
+
+
+def pack_results(results):
+    """lgicp_result list -> [n, RESULT_WIDTH] float64 (keys are exact up to 2^53)."""
+    out = np.zeros((len(results), RESULT_WIDTH), np.float64)
+    for i, r in enumerate(results):
+        row = out[i]
+        row[0], row[1], row[2], row[3] = r.key_from, r.key_to, r.status, r.iterations
+        row[4] = r.fitness
+        row[5:21] = r.T_icp[:]
+        row[21:30] = r.delta_R[:]
+        row[30:33] = r.delta_t[:]
+        row[33:69] = r.covariance[:]
+        row[69:105] = r.information[:]
+    return out
+
+
+def gather_records(records, dist, rank, world, device=None):
+    """Gather per-rank [n_r, RESULT_WIDTH] arrays to rank 0 (ranks may hold different n_r).
+    Returns the concatenated array on rank 0, None elsewhere."""
+    import torch
+    if world == 1 or dist is None:
+        return records
+    dev = torch.device("cpu") if device is None else device
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts[rank] = records.shape[0]
+    dist.all_reduce(counts)
+    n_max = int(counts.max().item())
+    buf = torch.zeros((n_max, RESULT_WIDTH), dtype=torch.float64, device=dev)
+    if records.shape[0]:
+        buf[: records.shape[0]] = torch.from_numpy(np.ascontiguousarray(records)).to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0)
+    if rank != 0:
+        return None
+    parts = [gathered[r][: int(counts[r].item())].cpu().numpy() for r in range(world)]
+    return np.concatenate(parts, axis=0)

@@ -58,3 +58,14 @@ def test_no_device_fails_loudly():
     from lamp_amd import capi
     with pytest.raises(capi.LgicpError):
         capi.Context()
+
+
+def test_host_mirror_cpu_logic():
+    """C++ mirror of LoopComputation / IcpLoopComputation: parameter loading, reclosing filter,
+    edge creation, queue and status publishing (no GPU needed)."""
+    import subprocess
+    exe = os.path.join(ROOT, "lamp_amd", "host", "test_loop_computation")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "lamp_amd", "host")])
+    out = subprocess.check_output([exe, "--host-only"], timeout=60)
+    assert b"host_only" in out

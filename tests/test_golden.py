@@ -1,0 +1,86 @@
+"""Committed golden vectors (tests/golden, made by tests/make_golden.py): the oracle must keep
+reproducing them on CPU, and the HIP path must match them on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import fixtures as F
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_oracle_reproduces_plane_golden():
+    g = _load("plane_ap.npz")
+    xyz, nrm = F.generate_plane()
+    assert np.array_equal(O.normalize_cloud(xyz), g["normalized"])
+    assert np.allclose(O.compute_ap(g["normalized"], nrm, np.arange(100), np.eye(4)), g["Ap"], atol=1e-12)
+    assert abs(g["Ap"][0, 0] - 56.77534) < 1e-5 and abs(g["Ap"][5, 5] - 100) < 1e-5
+    assert np.allclose(O.icp_observability(xyz, nrm), g["observability"], atol=1e-9)
+
+
+def test_oracle_reproduces_corner_golden():
+    g = _load("corner_alignment.npz")
+    corner, cn = F.generate_corner()
+    moved, mn, T = F.shifted_corner()
+    for name, solver in (("bfgs", O.SOLVER_BFGS), ("gn", O.SOLVER_GN)):
+        r = O.gicp_align(O.base_gicp_params(solver=solver, use_kdtree=0), moved, mn, corner, cn,
+                         g["guess"], trace_cap=8)
+        assert r["iterations"] == int(g[f"{name}_iterations"])
+        assert np.allclose(r["T"], g[f"{name}_T"], atol=1e-6)
+        n_it = len(g[f"{name}_trace_idx"])
+        assert np.array_equal(r["trace_idx"][:n_it][0], g[f"{name}_trace_idx"][0])
+        # the reference's own expectation for this fixture: T^-1 = (1, -0.001, 0) to 1e-3
+        assert np.allclose(np.linalg.inv(r["T"].astype(np.float64))[:3, 3], [1, -0.001, 0], atol=1e-3)
+
+
+def test_oracle_reproduces_room_golden():
+    g = _load("room_pair_2000.npz")
+    src, sn, tgt, tn, T = F.make_pair(2000, 1234, rot_deg=3.0, trans=0.25)
+    idx, d2 = O.nn_brute(src, tgt)
+    assert np.array_equal(idx, g["nn_idx_iter0"]) and np.array_equal(d2, g["nn_d2_iter0"])
+    ik, dk = O.kdtree_knn(src, tgt, 1)
+    assert np.array_equal(ik[:, 0], g["nn_idx_iter0"])
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden_vectors():
+    from lamp_amd import capi
+    c = capi.Context(init_method=capi.INIT_IDENTITY)
+    try:
+        g = _load("room_pair_2000.npz")
+        src, sn, tgt, tn, T = F.make_pair(2000, 1234, rot_deg=3.0, trans=0.25)
+        idx, d2 = c.nn_search(np.eye(4), src, tgt)
+        assert np.array_equal(idx, g["nn_idx_iter0"])
+        assert np.array_equal(d2.view(np.uint32), g["nn_d2_iter0"].view(np.uint32))
+        r = c.align(src, sn, tgt, tn, np.eye(4))
+        assert r["iterations"] == int(g["iterations"])
+        assert np.allclose(r["T"], g["T"], atol=2e-6)
+        cov = c.covariances_knn(src, 20, 1e-3)[:64]
+        assert np.abs(cov - g["cov_knn_src_first64"]).max() < 1e-6
+
+        g = _load("corner_alignment.npz")
+        corner, cn = F.generate_corner()
+        moved, mn, _ = F.shifted_corner()
+        # first-iteration correspondences: T = identity on guess*source
+        q = O.transform_points_f32(g["guess"], moved)
+        idx, _ = c.nn_search(np.eye(4), q, corner)
+        gated = g["gn_trace_idx"][0]
+        assert np.array_equal(idx[gated >= 0], gated[gated >= 0])
+        r = c.align(moved, mn, corner, cn, g["guess"])
+        assert np.allclose(r["T"], g["gn_T"], atol=1e-5)
+        Ap = c.compute_ap(moved, cn, g["corr"], g["gn_T"], normalize=True)
+        assert np.allclose(Ap, g["Ap"], rtol=1e-9, atol=1e-9 * np.abs(g["Ap"]).max())
+
+        g = _load("plane_ap.npz")
+        xyz, nrm = F.generate_plane()
+        Ap = c.compute_ap(xyz, nrm, np.arange(100), np.eye(4), normalize=True)
+        assert np.allclose(Ap, g["Ap"], atol=1e-9)
+        assert np.allclose(c.covariances_from_normals(nrm), g["cov_from_normals"], atol=1e-15)
+    finally:
+        c.close()

@@ -268,3 +268,15 @@ def test_submit_reject_reasons():
         assert c.submit([(20, 10)])[0].status == capi.PAIR_TRANSFORM
     finally:
         c.close()
+
+
+def test_host_mirror_reference_style_tests():
+    """The C++ GpuIcpLoopComputation driven like the reference's gtest fixtures
+    (test_loop_computation.cc:125-182, test_icp_computation.cpp:53-162)."""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "lamp_amd", "host", "test_loop_computation")
+    out = subprocess.check_output([exe], timeout=110)
+    d = json.loads(out.decode().strip().splitlines()[-1])
+    assert d["batch_edges"] == 100
+    assert abs(d["perform_alignment_t"][0] - 1) < 1e-3
