@@ -22,6 +22,24 @@ sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32 peak (packed FMA), per GPU
 
+def pmc_traffic(kernel, config):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this same
+    workload (FETCH_SIZE and WRITE_SIZE are collected in their own profiler passes, not inside
+    this process).  None when no summary for the config has been recorded."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(
+            os.path.join(ROOT, "profiles")) else []:
+        if name.endswith("_pmc_summary.json") and f"_{config.lower()}_" in name:
+            best = os.path.join(ROOT, "profiles", name)
+    if best is None:
+        return None
+    try:
+        k = json.load(open(best))["kernels"].get(kernel, {})
+        return k.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(work, n_sample, threads):
     """The CPU oracle (kd-tree lookups, BFGS: the reference's configuration) on the first
     n_sample pairs of the same workload, one pair per host thread."""
@@ -174,7 +192,7 @@ def main():
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic("lgicp::nn_kernel<4>", args.config),
                 "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": nn_launches / args.steps,
                 "flops_per_launch": flops_per_launch,

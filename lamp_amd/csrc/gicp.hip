@@ -478,6 +478,11 @@ hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
 // Ap = sum H^T H, H = [(a x R n)^T, (R n)^T] (PointCloudUtils.cc:115-163) with a = normalised
 // un-accumulated source point (PointCloudUtils.cc:39-59), n = un-accumulated target normal of
 // its correspondence (zero when the index lies beyond that scan, PointCloudUtils.cc:138-146).
+//
+// POINT2POINT mode instead accumulates H = sum J^T J with the closed-form 3x6 Jacobian of
+// ComputeICPCovariancePointPoint (loop_closure/src/IcpLoopComputation.cc:770-882) over the
+// aligned points; roll/pitch/yaw are the ZYX Euler angles of the final rotation.
+template <int POINT2POINT>
 __global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
     const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
     const PairState* __restrict__ st, const int4* __restrict__ bmap,
@@ -501,6 +506,23 @@ __global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
   const float fac = S1.factor;
   const float ox = -fac * S1.centroid[0], oy = -fac * S1.centroid[1], oz = -fac * S1.centroid[2];
 
+  // gu::Rot3::Roll/Pitch/Yaw of the final rotation (POINT2POINT only)
+  double cr = 1, sr = 0, cp = 1, sp = 0, cy = 1, sy = 0;
+  if (POINT2POINT) {
+    const double pitch = -asin(R[6]);
+    double roll, yaw;
+    if (cos(pitch) > 1e-6) {
+      roll = atan2(R[7], R[8]);
+      yaw = atan2(R[3], R[0]);
+    } else {
+      roll = atan2(-R[5], R[4]);
+      yaw = 0.0;
+    }
+    sincos(roll, &sr, &cr);
+    sincos(pitch, &sp, &cp);
+    sincos(yaw, &sy, &cy);
+  }
+
   double acc[NPOST];
 #pragma unroll
   for (int i = 0; i < NPOST; ++i) acc[i] = 0.0;
@@ -520,7 +542,44 @@ __global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
       acc[1] += 1.0;
       j = (int)(key & 0xFFFFFFFFu);
     }
-    if (i < S1.n && j >= 0) {
+    if (POINT2POINT) {
+      const double p_x = ax, p_y = ay, p_z = az;
+      const double t_x = tf[3], t_y = tf[7], t_z = tf[11];
+      const double ex = (t_x - p_x + p_z * cp - p_x * cy * sp + p_y * sp * sy);
+      const double ey = (p_y - t_y + p_x * (sr * sy - cp * cr * cy) +
+                         p_y * (cy * sr + cp * cr * sy) - p_z * cr * sp);
+      const double ez = (t_z - p_z + p_x * (cr * sy + cp * cy * sr) +
+                         p_y * (cr * cy - cp * sr * sy) + p_z * sp * sr);
+      double J[3][6];
+      J[0][0] = 0.0;
+      J[0][1] = -2.0 * (p_z * sp + p_x * cp * cy - p_y * cp * sy) * ex;
+      J[0][2] = 2.0 * (p_y * cy * sp + p_x * sp * sy) * ex;
+      J[0][3] = 2.0 * t_x - 2.0 * p_x + 2.0 * p_z * cp - 2.0 * p_x * cy * sp + 2.0 * p_y * sp * sy;
+      J[0][4] = 0.0;
+      J[0][5] = 0.0;
+      J[1][0] = 2.0 * (p_x * (cr * sy + cp * cy * sr) + p_y * (cr * cy - cp * sr * sy) +
+                       p_z * sp * sr) * ey;
+      J[1][1] = -2.0 * (p_z * cp * cr - p_x * cr * cy * sp + p_y * cr * sp * sy) * ey;
+      J[1][2] = 2.0 * (p_x * (cy * sr + cp * cr * sy) - p_y * (sr * sy - cp * cr * cy)) * ey;
+      J[1][3] = 0.0;
+      J[1][4] = 2.0 * t_y - 2.0 * p_y - 2.0 * p_x * (sr * sy - cp * cr * cy) -
+                2.0 * p_y * (cy * sr + cp * cr * sy) + 2.0 * p_z * cr * sp;
+      J[1][5] = 0.0;
+      J[2][0] = -2.0 * (p_x * (sr * sy - cp * cr * cy) + p_y * (cy * sr + cp * cr * sy) -
+                        p_z * cr * sp) * ez;
+      J[2][1] = 2.0 * (p_z * cp * sr - p_x * cy * sp * sr + p_y * sp * sr * sy) * ez;
+      J[2][2] = 2.0 * (p_x * (cr * cy - cp * sr * sy) - p_y * (cr * sy + cp * cy * sr)) * ez;
+      J[2][3] = 0.0;
+      J[2][4] = 0.0;
+      J[2][5] = 2.0 * t_z - 2.0 * p_z + 2.0 * p_x * (cr * sy + cp * cy * sr) +
+                2.0 * p_y * (cr * cy - cp * sr * sy) + 2.0 * p_z * sp * sr;
+      int s_ = 3;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c)
+          acc[s_++] += J[0][r] * J[0][c] + J[1][r] * J[1][c] + J[2][r] * J[2][c];
+    } else if (i < S1.n && j >= 0) {
       // normalised query point: pcl::transformPointCloud with diag(factor) and -factor*centroid
       const float4 s = S1.xyz[i];
       const double a0 = (double)(((fac * s.x + 0.f * s.y) + 0.f * s.z) + ox);
@@ -563,11 +622,15 @@ __global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
 }
 
 hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
-                              const int4* bmap, int n_blocks, double* partials,
+                              const int4* bmap, int n_blocks, double* partials, bool point2point,
                               hipStream_t stream) {
   if (n_blocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(post_reduce_kernel, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
-                     pairs, st, bmap, partials);
+  if (point2point)
+    hipLaunchKernelGGL(post_reduce_kernel<1>, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
+                       pairs, st, bmap, partials);
+  else
+    hipLaunchKernelGGL(post_reduce_kernel<0>, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
+                       pairs, st, bmap, partials);
   return hipGetLastError();
 }
 

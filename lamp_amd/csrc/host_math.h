@@ -323,5 +323,32 @@ inline void point_plane_covariance(const double Ap[36], double rot_sigma, double
     }
 }
 
+// tail of ComputeICPCovariancePointPoint (IcpLoopComputation.cc:883-905) given H = sum J^T J:
+// cov = H^-1 * fitness, eigenvalues clamped to [1e-3, 1e3].  The reference uses the general
+// Eigen::EigenSolver and recomposes V L V^-1; for this (numerically symmetric) matrix that is
+// the symmetric decomposition V L V^T.
+inline void point_point_covariance(const double H[36], double fitness, double cov[36]) {
+  double inv[36];
+  inverse6(H, inv);
+  bool finite = true;
+  for (int i = 0; i < 36; ++i) {
+    cov[i] = inv[i] * fitness;
+    finite = finite && std::isfinite(cov[i]);
+  }
+  if (!finite) {  // "Failed to find eigen values": identity * upper bound (:892-896)
+    for (int i = 0; i < 36; ++i) cov[i] = (i % 7 == 0) ? 1000.0 : 0.0;
+    return;
+  }
+  double ev[6], V[36];
+  sym_eig6(cov, ev, V);
+  for (int i = 0; i < 6; ++i) ev[i] = ev[i] < 0.001 ? 0.001 : (ev[i] > 1000 ? 1000 : ev[i]);
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += V[a * 6 + k] * ev[k] * V[b * 6 + k];
+      cov[a * 6 + b] = s;
+    }
+}
+
 }  // namespace hm
 }  // namespace lgicp

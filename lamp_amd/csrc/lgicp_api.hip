@@ -557,6 +557,8 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   HIP_TRY(ctx, hipEventRecord(ev_post1, st));
   HIP_TRY(ctx, launch_post_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
                                   ctx->d_bmap_red.p, (int)h_bmap_red.size(), ctx->d_partials.p,
+                                  cfg.covariance_method == LGICP_COV_POINT2POINT &&
+                                      !cfg.use_fixed_covariances,
                                   st));
   HIP_TRY(ctx, hipEventRecord(ev_post2, st));
   std::vector<double> h_post((size_t)n_pairs * RED_MAX_CHUNKS * NPOST);
@@ -654,6 +656,9 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
     if (cfg.use_fixed_covariances) {
       hm::fixed_covariance(cfg.laser_lc_rot_sigma, cfg.laser_lc_trans_sigma, r.covariance);
       hm::inverse6(r.covariance, r.information);
+    } else if (cfg.covariance_method == LGICP_COV_POINT2POINT) {
+      hm::point_point_covariance(Ap /* = H */, r.fitness, r.covariance);
+      hm::inverse6(r.covariance, r.information);
     } else {
       hm::point_plane_covariance(Ap, cfg.laser_lc_rot_sigma, cfg.laser_lc_trans_sigma,
                                  r.covariance);
@@ -677,8 +682,6 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
                 "init_method %d (feature-based initial alignment) is not available on the device "
                 "path yet",
                 cfg.init_method);
-  if (cfg.covariance_method == LGICP_COV_POINT2POINT && !cfg.use_fixed_covariances)
-    return fail(ctx, LGICP_E_UNSUPPORTED, "POINT2POINT covariance is not available yet");
   HIP_TRY(ctx, hipSetDevice(cfg.device));
   ctx->stats.nn_ms = ctx->stats.reduce_ms = ctx->stats.solve_ms = ctx->stats.cov_ms =
       ctx->stats.post_ms = ctx->stats.total_ms = 0;

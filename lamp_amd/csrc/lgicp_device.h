@@ -113,7 +113,7 @@ hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
                              const int* n_chunks, const double* partials, SolveParams sp,
                              int* n_done, hipStream_t stream);
 hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
-                              const int4* bmap, int n_blocks, double* partials,
+                              const int4* bmap, int n_blocks, double* partials, bool point2point,
                               hipStream_t stream);
 
 hipError_t launch_cov_knn(const float4* xyz, int n, int n_pad, int k, double eps, double* cov6,

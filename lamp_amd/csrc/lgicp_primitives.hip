@@ -197,7 +197,7 @@ int lgicp_compute_ap(lgicp_ctx* ctx, const float* query_xyz, size_t n_query,
   HIP_TRY(ctx, hipMemcpy(d_bmap, hb, sizeof(int4) * chunks, hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(d_ids, &zero, sizeof(int), hipMemcpyHostToDevice));
   if (normalize_query) HIP_TRY(ctx, launch_normalize_constants(d_clouds, d_ids, 1, st));
-  HIP_TRY(ctx, launch_post_reduce(d_clouds, d_pair, d_state, d_bmap, chunks, d_part, st));
+  HIP_TRY(ctx, launch_post_reduce(d_clouds, d_pair, d_state, d_bmap, chunks, d_part, false, st));
   std::vector<double> hpart((size_t)chunks * NPOST);
   HIP_TRY(ctx, hipMemcpyAsync(hpart.data(), d_part, sizeof(double) * hpart.size(),
                               hipMemcpyDeviceToHost, st));

@@ -280,3 +280,28 @@ def test_host_mirror_reference_style_tests():
     d = json.loads(out.decode().strip().splitlines()[-1])
     assert d["batch_edges"] == 100
     assert abs(d["perform_alignment_t"][0] - 1) < 1e-3
+
+
+def test_submit_point2point_covariance_matches_oracle():
+    """ComputeICPCovariancePointPoint (IcpLoopComputation.cc:770-908), config value 0."""
+    from lamp_amd import capi
+    c = capi.Context(init_method=capi.INIT_IDENTITY, covariance_method=capi.COV_POINT2POINT)
+    try:
+        src, sn, tgt, tn, T = F.make_pair(5000, 55, rot_deg=3.0, trans=0.3)
+        _register(c, 10, tgt, tn)
+        _register(c, 20, src, sn)
+        d = capi.result_to_dict(c.submit([(20, 10)])[0])
+        ident = O.pose_from_quat([1, 0, 0, 0], [0, 0, 0])
+        ref = O.perform_alignment(O.base_icp_params(init_method=O.INIT_IDENTITY, solver=O.SOLVER_GN,
+                                                    covariance_method=O.COV_POINT2POINT),
+                                  src, sn, tgt, tn, src, tn, ident)
+        assert d["status"] == ref["status"] == 0
+        # the covariance is evaluated at the GPU's own final transform: feed that to the oracle
+        aligned = O.transform_points_f32(d["T_icp"], src)
+        cov = O.icp_cov_point_point(aligned, d["T_icp"], d["fitness"])
+        assert np.allclose(d["covariance"], cov, rtol=1e-6, atol=1e-9)
+        assert np.allclose(d["covariance"], ref["covariance"], rtol=1e-3, atol=1e-6)
+        assert np.all(np.linalg.eigvalsh(d["covariance"]) >= 1e-3 - 1e-12)
+        assert np.allclose(d["information"] @ d["covariance"], np.eye(6), atol=1e-8)
+    finally:
+        c.close()
