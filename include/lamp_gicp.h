@@ -198,6 +198,12 @@ int lgicp_compute_ap(lgicp_ctx* ctx, const float* query_xyz, size_t n_query,
                      const float* ref_normals, size_t n_ref, const int32_t* corr, size_t n_corr,
                      const float T[16], int normalize_query, double Ap[36]);
 
+/* lamp_utils::ComputeFeatures (lamp_utils/src/PointCloudUtils.cc:98-113): FPFH (PCL
+ * FPFHSignature33, 11 bins each of f1 | f2 | f3) at the keypoints, search surface = the whole
+ * cloud with its normals, radius search.  out is [n_key][33] floats. */
+int lgicp_fpfh(lgicp_ctx* ctx, const float* surface_xyz, const float* surface_normals, size_t n,
+               const float* keypoints_xyz, size_t n_key, double radius, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ COV_POINT2POINT, COV_POINT2PLANE = 0, 1
 EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_error",
            "lgicp_add_keyframe", "lgicp_add_pose", "lgicp_has_keyframe", "lgicp_has_pose",
            "lgicp_submit", "lgicp_get_stats", "lgicp_nn_search", "lgicp_covariances_from_normals",
-           "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap"]
+           "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh"]
 
 
 class Config(C.Structure):
@@ -99,6 +99,8 @@ def lib():
                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.lgicp_compute_ap.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+        L.lgicp_fpfh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                 C.c_size_t, C.c_double, C.c_void_p]
         _lib = L
     return _lib
 
@@ -217,6 +219,14 @@ class Context:
                                       C.byref(it), C.byref(fit)))
         return {"T": T.reshape(4, 4), "converged": bool(conv.value), "iterations": it.value,
                 "fitness": fit.value}
+
+    def fpfh(self, surface_xyz, surface_normals, keypoints_xyz, radius):
+        sx, sn = _f32(surface_xyz).reshape(-1, 3), _f32(surface_normals).reshape(-1, 3)
+        kx = _f32(keypoints_xyz).reshape(-1, 3)
+        out = np.empty((len(kx), 33), np.float32)
+        self._check(lib().lgicp_fpfh(self._h, _ptr(sx), _ptr(sn), len(sx), _ptr(kx), len(kx),
+                                     float(radius), _ptr(out)))
+        return out
 
     def compute_ap(self, query, ref_normals, corr, T, normalize=True):
         q, rn = _f32(query).reshape(-1, 3), _f32(ref_normals).reshape(-1, 3)

@@ -119,4 +119,9 @@ hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, cons
 hipError_t launch_cov_knn(const float4* xyz, int n, int n_pad, int k, double eps, double* cov6,
                           hipStream_t stream);
 
+// FPFH at n_key keypoints over a surface of n points (radius^2 = r2); need[n], spfh[n*33]
+// are scratch, out is [n_key][33]
+hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float4* keys, int n_key,
+                       float r2, unsigned char* need, float* spfh, float* out, hipStream_t stream);
+
 }  // namespace lgicp

@@ -211,4 +211,29 @@ int lgicp_compute_ap(lgicp_ctx* ctx, const float* query_xyz, size_t n_query,
   return LGICP_OK;
 }
 
+int lgicp_fpfh(lgicp_ctx* ctx, const float* surface_xyz, const float* surface_normals, size_t n,
+               const float* keypoints_xyz, size_t n_key, double radius, float* out) {
+  if (!ctx || (n && (!surface_xyz || !surface_normals)) || (n_key && (!keypoints_xyz || !out)))
+    return fail(ctx, LGICP_E_INVALID, "null argument");
+  if (n > (size_t)1 << 28 || n_key > (size_t)1 << 24) return fail(ctx, LGICP_E_INVALID, "too large");
+  if (n_key == 0) return LGICP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  Dev d;
+  float4* d_s = upload_points(d, surface_xyz, n, (int)std::max<size_t>(n, 1), 1.f);
+  float4* d_n = upload_points(d, surface_normals, n, (int)std::max<size_t>(n, 1), 0.f);
+  float4* d_k = upload_points(d, keypoints_xyz, n_key, (int)n_key, 1.f);
+  unsigned char* d_need = d.alloc<unsigned char>(n);
+  float* d_spfh = d.alloc<float>(n * 33);
+  float* d_out = d.alloc<float>(n_key * 33);
+  if (!d_s || !d_n || !d_k || !d_need || !d_spfh || !d_out)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, hipMemsetAsync(d_spfh, 0, sizeof(float) * std::max<size_t>(n, 1) * 33, ctx->stream));
+  HIP_TRY(ctx, launch_fpfh(d_s, d_n, (int)n, d_k, (int)n_key, (float)(radius * radius), d_need,
+                           d_spfh, d_out, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * n_key * 33, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LGICP_OK;
+}
+
 }  // extern "C"

@@ -126,6 +126,12 @@ void lo_compute_ap(const float* query_normalized, int n_query, const float* ref_
 /* PointCloudUtils.cc:165-196 (normals taken from the cloud; ascending eigenvalues) */
 void lo_icp_observability(const float* xyz, const float* normals, int n, double eig[3]);
 
+/* ------------------------------------------------------------------ FPFH */
+/* lamp_utils::ComputeFeatures (PointCloudUtils.cc:98-113): PCL FPFHEstimationOMP, input =
+ * keypoints, surface = full cloud.  out is [n_key][33] floats = [f1 | f2 | f3] */
+void lo_fpfh(const float* surface_xyz, const float* surface_normals, int n,
+             const float* keypoints_xyz, int n_key, double radius, float* out);
+
 /* ------------------------------------------------------------------ IcpLoopComputation */
 /* IcpLoopComputation.cc:707-768 */
 void lo_icp_cov_point_plane(const float* scan1_xyz, int n1, const float* scan2_normals, int n2,

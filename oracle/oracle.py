@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "liblamp_oracle.so")
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds)."""
-    srcs = ["lo_linalg.c", "lo_kdtree.c", "lo_gicp.c", "lo_icp_loop.c", "lamp_oracle.h"]
+    srcs = ["lo_linalg.c", "lo_kdtree.c", "lo_gicp.c", "lo_icp_loop.c", "lo_fpfh.c", "lamp_oracle.h"]
     if not force and os.path.exists(_LIB_PATH):
         newest = max(os.path.getmtime(os.path.join(_HERE, s)) for s in srcs)
         if os.path.getmtime(_LIB_PATH) >= newest:
@@ -267,6 +267,14 @@ def icp_cov_point_point(aligned_xyz, T, fitness):
     lib().lo_icp_cov_point_point(_p(a, C.c_float), len(a), _p(T, C.c_float), C.c_double(fitness),
                                  _p(cov, C.c_double))
     return cov.reshape(6, 6)
+
+
+def fpfh(surface_xyz, surface_normals, keypoints_xyz, radius):
+    sx, sn, kx = _f32(surface_xyz), _f32(surface_normals), _f32(keypoints_xyz)
+    out = np.empty((len(kx), 33), np.float32)
+    lib().lo_fpfh(_p(sx, C.c_float), _p(sn, C.c_float), len(sx), _p(kx, C.c_float), len(kx),
+                  C.c_double(radius), _p(out, C.c_float))
+    return out
 
 
 def pose_from_quat(q_wxyz, t):

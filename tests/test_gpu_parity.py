@@ -305,3 +305,25 @@ def test_submit_point2point_covariance_matches_oracle():
         assert np.allclose(d["information"] @ d["covariance"], np.eye(6), atol=1e-8)
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------ K4: FPFH
+def test_fpfh_matches_oracle(ctx):
+    """lamp_utils::ComputeFeatures (PointCloudUtils.cc:98-113).  The reference pins only the
+    descriptor count (test_point_cloud_utils.cc:153-170): values are checked against the CPU
+    restatement of PCL's published algorithm (parity unpinned)."""
+    corner, cn = F.generate_corner()
+    kp = corner[[33, 133, 233]]
+    got = ctx.fpfh(corner, cn, kp, 1.0)
+    ref = O.fpfh(corner, cn, kp, 1.0)
+    assert got.shape == (3, 33)
+    assert np.allclose(got.reshape(3, 3, 11).sum(-1), 100, atol=1e-3)
+    assert np.allclose(got, ref, atol=2e-3)
+    xyz, nrm = F.random_room_scan(6000, 9)
+    kp = np.vstack([xyz[::400], [[0.3, 0.2, 1.0]]])          # keypoints on and off the surface
+    got = ctx.fpfh(xyz, nrm, kp, 2.0)
+    ref = O.fpfh(xyz, nrm, kp, 2.0)
+    assert np.allclose(got, ref, atol=5e-3), np.abs(got - ref).max()
+    # a keypoint far from everything has an all-zero descriptor
+    far = ctx.fpfh(xyz, nrm, np.array([[100.0, 100.0, 100.0]]), 2.0)
+    assert np.all(far == 0)

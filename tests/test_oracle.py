@@ -226,3 +226,22 @@ def test_pose_algebra():
     inv = O.pose_inverse(p)
     Ri, ti = O.pose_to_np(inv)
     assert np.allclose(Ri, R.T) and np.allclose(ti, -R.T @ t)
+
+
+def test_fpfh_oracle_properties():
+    # lamp_utils/test/test_point_cloud_utils.cc:153-170 pins the count only (3 descriptors)
+    corner, cn = F.generate_corner()
+    kp = corner[[33, 133, 233]]
+    f = O.fpfh(corner, cn, kp, 1.0)
+    assert f.shape == (3, 33)
+    assert np.allclose(f.reshape(3, 3, 11).sum(-1), 100, atol=1e-3)
+    # descriptors are invariant under a rigid motion of cloud + normals + keypoints (checked on
+    # a noisy scan: on the grid fixture angles and radii sit exactly on bin / radius edges)
+    xyz, nrm = F.random_room_scan(1500, 3)
+    kp = xyz[::300]
+    f = O.fpfh(xyz, nrm, kp, 2.0)
+    R = F.rot_zyx(0.3, -0.2, 0.7)
+    x2 = (xyz.astype(np.float64) @ R.T + [1, 2, 3]).astype(np.float32)
+    n2 = (nrm.astype(np.float64) @ R.T).astype(np.float32)
+    f2 = O.fpfh(x2, n2, x2[::300], 2.0)
+    assert np.abs(f - f2).max() < 0.5
