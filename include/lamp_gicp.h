@@ -132,6 +132,8 @@ typedef struct lgicp_result {
   double covariance[36];      /* edge.covariance, order rotX,rotY,rotZ,x,y,z */
   double information[36];     /* Ap of ComputeAp_ForPoint2PlaneICP / 0.05^2 (POINT2PLANE) or
                                  inverse of covariance otherwise; zero when not computed */
+  float T_init[16];           /* the guess handed to GICP (after SAC-IA when init is FEATURES) */
+  double init_fitness;        /* sac_ia.getFitnessScore() (IcpLoopComputation.cc:701); 0 otherwise */
 } lgicp_result;
 
 typedef struct lgicp_stats {
@@ -203,6 +205,21 @@ int lgicp_compute_ap(lgicp_ctx* ctx, const float* query_xyz, size_t n_query,
  * cloud with its normals, radius search.  out is [n_key][33] floats. */
 int lgicp_fpfh(lgicp_ctx* ctx, const float* surface_xyz, const float* surface_normals, size_t n,
                const float* keypoints_xyz, size_t n_key, double radius, float* out);
+
+/* lamp_utils::ComputeKeypoints with normals (PointCloudUtils.cc:78-96): Harris3D keypoints with
+ * the context's harris_* parameters.  Writes up to `capacity` indices (ascending) and the total
+ * count. */
+int lgicp_harris_keypoints(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
+                           int32_t* idx_out, size_t capacity, size_t* count);
+/* IcpLoopComputation::GetSacInitialAlignment (IcpLoopComputation.cc:650-705): Harris keypoints
+ * and FPFH descriptors of both clouds on the device, SAC-IA (sac_iterations, 5 candidate
+ * correspondences) on the host.  guess is scored as the first hypothesis when it is not the
+ * identity.  fitness_score = getFitnessScore() of the keypoint alignment (DBL_MAX when a cloud
+ * yields fewer than 3 / 1 keypoints). */
+int lgicp_sac_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const float* src_normals,
+                                size_t n_src, const float* tgt_xyz, const float* tgt_normals,
+                                size_t n_tgt, const float guess[16], float T_out[16],
+                                double* fitness_score);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,8 @@ COV_POINT2POINT, COV_POINT2PLANE = 0, 1
 EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_error",
            "lgicp_add_keyframe", "lgicp_add_pose", "lgicp_has_keyframe", "lgicp_has_pose",
            "lgicp_submit", "lgicp_get_stats", "lgicp_nn_search", "lgicp_covariances_from_normals",
-           "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh"]
+           "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh",
+           "lgicp_harris_keypoints", "lgicp_sac_initial_alignment"]
 
 
 class Config(C.Structure):
@@ -50,7 +51,8 @@ class Result(C.Structure):
                 ("n_correspondences", C.c_int32), ("T_icp", C.c_float * 16),
                 ("delta_R", C.c_double * 9), ("delta_t", C.c_double * 3),
                 ("delta_q", C.c_double * 4), ("fitness", C.c_double),
-                ("covariance", C.c_double * 36), ("information", C.c_double * 36)]
+                ("covariance", C.c_double * 36), ("information", C.c_double * 36),
+                ("T_init", C.c_float * 16), ("init_fitness", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -101,6 +103,11 @@ def lib():
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
         L.lgicp_fpfh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                  C.c_size_t, C.c_double, C.c_void_p]
+        L.lgicp_harris_keypoints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.lgicp_sac_initial_alignment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                  C.c_void_p, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -228,6 +235,24 @@ class Context:
                                      float(radius), _ptr(out)))
         return out
 
+    def harris_keypoints(self, xyz, normals):
+        x, nn = _f32(xyz).reshape(-1, 3), _f32(normals).reshape(-1, 3)
+        idx = np.empty(len(x), np.int32)
+        cnt = C.c_size_t()
+        self._check(lib().lgicp_harris_keypoints(self._h, _ptr(x), _ptr(nn), len(x), _ptr(idx),
+                                                 len(idx), C.byref(cnt)))
+        return idx[: cnt.value].copy()
+
+    def sac_initial_alignment(self, src, src_n, tgt, tgt_n, guess=None):
+        a = [_f32(v).reshape(-1, 3) for v in (src, src_n, tgt, tgt_n)]
+        g = _f32(np.eye(4) if guess is None else guess).reshape(16)
+        T = np.empty(16, np.float32)
+        fit = C.c_double()
+        self._check(lib().lgicp_sac_initial_alignment(self._h, _ptr(a[0]), _ptr(a[1]), len(a[0]),
+                                                      _ptr(a[2]), _ptr(a[3]), len(a[2]), _ptr(g),
+                                                      _ptr(T), C.byref(fit)))
+        return T.reshape(4, 4), fit.value
+
     def compute_ap(self, query, ref_normals, corr, T, normalize=True):
         q, rn = _f32(query).reshape(-1, 3), _f32(ref_normals).reshape(-1, 3)
         corr = np.ascontiguousarray(corr, np.int32)
@@ -236,6 +261,12 @@ class Context:
         self._check(lib().lgicp_compute_ap(self._h, _ptr(q), len(q), _ptr(rn), len(rn), _ptr(corr),
                                            len(corr), _ptr(T), int(normalize), _ptr(Ap)))
         return Ap.reshape(6, 6)
+
+
+def pair_seed(key_from, key_to):
+    """Sampling seed lgicp_submit gives the SAC-IA of one candidate."""
+    return (0x5AC1A000 ^ ((key_from * 2654435761) & 0xFFFFFFFF) ^ ((key_to * 40503) & 0xFFFFFFFF)) \
+        & 0xFFFFFFFF
 
 
 def result_to_dict(r):
@@ -248,4 +279,6 @@ def result_to_dict(r):
         "delta_q": np.array(r.delta_q), "fitness": r.fitness,
         "covariance": np.array(r.covariance).reshape(6, 6),
         "information": np.array(r.information).reshape(6, 6),
+        "T_init": np.array(r.T_init, dtype=np.float32).reshape(4, 4),
+        "init_fitness": r.init_fitness,
     }

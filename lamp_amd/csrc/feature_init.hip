@@ -1,0 +1,180 @@
+// feature_init.hip — device side of the SAC-IA initial alignment
+// (IcpLoopComputation::GetSacInitialAlignment, loop_closure/src/IcpLoopComputation.cc:650-705).
+//
+// pcl::SampleConsensusInitialAlignment evaluates its hypotheses one after the other: draw three
+// source keypoints, give each a random one of its k nearest target descriptors, estimate the
+// rigid transform, score it by sum_i min(d_i^2 / 100, 1) with d_i the distance from the moved
+// source keypoint i to its nearest target keypoint, keep the first strictly lowest score.
+// Drawing and estimating do not depend on earlier scores, so all hypotheses are generated up
+// front on the host (sac_ia.h) and scored here in one launch, one workgroup per hypothesis; the
+// host then replays the "first strictly lower" selection.  The descriptor k-NN table (33-D,
+// squared L2, k = 5) is one more small exhaustive kernel.
+#include <algorithm>
+#include <cfloat>
+
+#include "lgicp_internal.h"
+#include "sac_ia.h"
+
+namespace lgicp {
+
+// nn[i][0..k) = indices of the k nearest target descriptors of source descriptor i
+__global__ __launch_bounds__(128) void feature_knn_kernel(const float* __restrict__ src_feat,
+                                                          int n_src,
+                                                          const float* __restrict__ tgt_feat,
+                                                          int n_tgt, int k,
+                                                          int* __restrict__ nn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_src) return;
+  float f[33];
+#pragma unroll
+  for (int b = 0; b < 33; ++b) f[b] = src_feat[(size_t)i * 33 + b];
+  float bd[8];
+  int bi[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bd[s] = __builtin_inff(), bi[s] = -1;
+  for (int j = 0; j < n_tgt; ++j) {
+    float d = 0;
+#pragma unroll
+    for (int b = 0; b < 33; ++b) {
+      const float e = f[b] - tgt_feat[(size_t)j * 33 + b];
+      d += e * e;
+    }
+    float worst = bd[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s)
+      if (s < k) worst = bd[s];
+    if (d < worst) {
+      float cd = d;
+      int ci = j;
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < k) {
+          const bool lt = cd < bd[s];
+          const float td = lt ? bd[s] : cd;
+          const int ti = lt ? bi[s] : ci;
+          bd[s] = lt ? cd : bd[s];
+          bi[s] = lt ? ci : bi[s];
+          cd = td;
+          ci = ti;
+        }
+    }
+  }
+  for (int s = 0; s < k; ++s) nn[(size_t)i * k + s] = bi[s];
+}
+
+// one workgroup per hypothesis: err = sum min(d2/100, 1), fit = sum d2
+__global__ __launch_bounds__(256) void sac_score_kernel(const float* __restrict__ hyp,
+                                                        const float4* __restrict__ src_kp,
+                                                        int n_src,
+                                                        const float4* __restrict__ tgt_kp,
+                                                        int n_tgt, float threshold,
+                                                        double* __restrict__ err_fit) {
+  __shared__ double sh[2][4];
+  const float* T = hyp + (size_t)blockIdx.x * 16;
+  float t[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) t[i] = T[i];
+  double err = 0, fit = 0;
+  for (int i = threadIdx.x; i < n_src; i += 256) {
+    const float4 p = src_kp[i];
+    const float x = ((t[0] * p.x + t[1] * p.y) + t[2] * p.z) + t[3];
+    const float y = ((t[4] * p.x + t[5] * p.y) + t[6] * p.z) + t[7];
+    const float z = ((t[8] * p.x + t[9] * p.y) + t[10] * p.z) + t[11];
+    float best = __builtin_inff();
+    for (int j = 0; j < n_tgt; ++j) {
+      const float4 q = tgt_kp[j];
+      const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      best = d < best ? d : best;
+    }
+    err += (double)((best <= threshold) ? best / threshold : 1.0f);  // TruncatedError
+    fit += (double)best;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    err += __shfl_xor(err, off);
+    fit += __shfl_xor(fit, off);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[0][wave] = err, sh[1][wave] = fit;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    err_fit[2 * (size_t)blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    err_fit[2 * (size_t)blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+}  // namespace lgicp
+
+namespace lgicp_detail {
+
+namespace {
+struct Scratch {
+  std::vector<void*> ptrs;
+  ~Scratch() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  T* alloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return (T*)p;
+  }
+};
+}  // namespace
+
+// SAC-IA on the keypoints/descriptors of two clouds.  score = getFitnessScore() of the
+// keypoint alignment, DBL_MAX when the source has fewer than 3 keypoints or the target none.
+int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
+                     const float guess[16], uint32_t seed, float T_out[16], double* score) {
+  std::memcpy(T_out, guess, sizeof(float) * 16);
+  *score = DBL_MAX;
+  const int n_src = (int)src.idx.size(), n_tgt = (int)tgt.idx.size();
+  if (n_src < 3 || n_tgt < 1) return LGICP_OK;
+  const int k = std::min(5, n_tgt);  // setCorrespondenceRandomness(5), IcpLoopComputation.cc:697
+  hipStream_t st = ctx->stream;
+  Scratch d;
+  float* d_sf = d.alloc<float>(src.feat.size());
+  float* d_tf = d.alloc<float>(tgt.feat.size());
+  int* d_nn = d.alloc<int>((size_t)n_src * k);
+  float4* d_sk = d.alloc<float4>(n_src);
+  float4* d_tk = d.alloc<float4>(n_tgt);
+  if (!d_sf || !d_tf || !d_nn || !d_sk || !d_tk) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  std::vector<float4> hs(n_src), ht(n_tgt);
+  for (int i = 0; i < n_src; ++i) hs[i] = make_float4(src.xyz[3 * i], src.xyz[3 * i + 1], src.xyz[3 * i + 2], 1.f);
+  for (int i = 0; i < n_tgt; ++i) ht[i] = make_float4(tgt.xyz[3 * i], tgt.xyz[3 * i + 1], tgt.xyz[3 * i + 2], 1.f);
+  HIP_TRY(ctx, hipMemcpyAsync(d_sf, src.feat.data(), sizeof(float) * src.feat.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tf, tgt.feat.data(), sizeof(float) * tgt.feat.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_sk, hs.data(), sizeof(float4) * n_src, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tk, ht.data(), sizeof(float4) * n_tgt, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lgicp::feature_knn_kernel, dim3((n_src + 127) / 128), dim3(128), 0, st, d_sf,
+                     n_src, d_tf, n_tgt, k, d_nn);
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<int> nn((size_t)n_src * k);
+  HIP_TRY(ctx, hipMemcpyAsync(nn.data(), d_nn, sizeof(int) * nn.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  const sac::Hypotheses hyp = sac::make_hypotheses(src.xyz.data(), n_src, tgt.xyz.data(), nn.data(),
+                                                   k, ctx->cfg.sac_iterations, guess, seed);
+  const int n_hyp = (int)(hyp.T.size() / 16);
+  if (n_hyp == 0) return LGICP_OK;
+  float* d_hyp = d.alloc<float>(hyp.T.size());
+  double* d_ef = d.alloc<double>((size_t)2 * n_hyp);
+  if (!d_hyp || !d_ef) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, hipMemcpyAsync(d_hyp, hyp.T.data(), sizeof(float) * hyp.T.size(), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lgicp::sac_score_kernel, dim3(n_hyp), dim3(256), 0, st, d_hyp, d_sk, n_src,
+                     d_tk, n_tgt, 100.0f, d_ef);
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<double> ef((size_t)2 * n_hyp);
+  HIP_TRY(ctx, hipMemcpyAsync(ef.data(), d_ef, sizeof(double) * ef.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  // the sequential rule: hypothesis 0 always, afterwards only a strictly lower error
+  int best = 0;
+  float lowest = (float)ef[0];
+  for (int h = 1; h < n_hyp; ++h)
+    if ((float)ef[2 * h] < lowest) lowest = (float)ef[2 * h], best = h;
+  std::memcpy(T_out, &hyp.T[(size_t)16 * best], sizeof(float) * 16);
+  *score = ef[2 * best + 1] / n_src;
+  return LGICP_OK;
+}
+
+}  // namespace lgicp_detail

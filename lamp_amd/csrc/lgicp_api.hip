@@ -476,6 +476,46 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   }
   HIP_TRY(ctx, launch_normalize_constants(ctx->d_clouds.p, ctx->d_ints.p + off_ids,
                                           (int)scan1_ids.size(), st));
+
+  // ---- FEATURES initialisation (IcpLoopComputation.cc:517-527, 650-705) ----------------------
+  // Harris keypoints and FPFH descriptors once per distinct cloud of the batch, SAC-IA per
+  // pair starting from the odometry guess; a pair whose keypoint fitness reaches the
+  // threshold is dropped before GICP.
+  std::vector<char> init_rejected((size_t)n_pairs, 0);
+  if (cfg.init_method == LGICP_INIT_FEATURES) {
+    std::map<int, CloudFeatures> feats;
+    for (int p = 0; p < n_pairs; ++p)
+      for (int c : {bp.pairs[p].src_cloud, bp.pairs[p].tgt_cloud})
+        if (!feats.count(c)) {
+          const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm,
+                                                h_clouds[c].n, &feats[c]);
+          if (rc != LGICP_OK) return rc;
+        }
+    for (int p = 0; p < n_pairs; ++p) {
+      const PairPlan& pp = bp.pairs[p];
+      float T0[16];
+      double score = 0;
+      // one fixed sampling sequence per (key_from, key_to): results do not depend on how the
+      // candidates were batched
+      const uint32_t seed = 0x5AC1A000u ^ (uint32_t)(cand[pp.cand].key_from * 2654435761ull) ^
+                            (uint32_t)(cand[pp.cand].key_to * 40503ull);
+      const int rc = sac_align_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], pp.guess,
+                                      seed, T0, &score);
+      if (rc != LGICP_OK) return rc;
+      out[pp.cand].init_fitness = score;
+      std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
+      if (!(score < cfg.sac_fitness_score_threshold)) {
+        init_rejected[p] = 1;
+        h_state[p].active = 0;
+        h_state[p].failed = 1;
+      }
+      if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
+                                hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state.p, h_state.data(), sizeof(PairState) * n_pairs,
+                                hipMemcpyHostToDevice, st));
+  }
   HIP_TRY(ctx, launch_guess_transform(ctx->d_clouds.p, ctx->d_pairs.p, n_pairs, max_src_n, st));
   HIP_TRY(ctx, hipEventRecord(ev_prep, st));
 
@@ -605,6 +645,11 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
     r.converged = s.converged;
     r.n_correspondences = s.m;
     std::memcpy(r.T_icp, s.Tfinal, sizeof(r.T_icp));
+    std::memcpy(r.T_init, h_pairs[p].guess, sizeof(r.T_init));
+    if (init_rejected[p]) {
+      r.status = LGICP_PAIR_INIT_REJECTED;
+      continue;
+    }
     S.outer_iterations += (uint64_t)s.iterations;
     S.nn_distance_evals +=
         (double)h_pairs[p].n_src * (double)h_pairs[p].n_tgt * (double)(s.iterations + 1);
@@ -677,9 +722,9 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   if (!ctx) return LGICP_E_INVALID;
   if (n && (!cand || !out)) return fail(ctx, LGICP_E_INVALID, "null argument");
   const lgicp_config& cfg = ctx->cfg;
-  if (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP)
+  if (cfg.init_method == LGICP_INIT_TEASERPP)
     return fail(ctx, LGICP_E_UNSUPPORTED,
-                "init_method %d (feature-based initial alignment) is not available on the device "
+                "init_method %d (TEASER++ initial alignment) is not available on the device "
                 "path yet",
                 cfg.init_method);
   HIP_TRY(ctx, hipSetDevice(cfg.device));
@@ -724,7 +769,10 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
       // initial guess (IcpLoopComputation.cc:495-543)
       pp.pose21_odom = hm::between(ctx->poses.at(c.key_to), ctx->poses.at(c.key_from));
       switch (cfg.init_method) {
-        case LGICP_INIT_ODOMETRY: guess_from_pose(pp.pose21_odom, true, pp.guess); break;
+        case LGICP_INIT_ODOMETRY:
+        case LGICP_INIT_FEATURES:  // SAC-IA starts from the odometry guess
+          guess_from_pose(pp.pose21_odom, true, pp.guess);
+          break;
         case LGICP_INIT_ODOM_ROTATION: guess_from_pose(pp.pose21_odom, false, pp.guess); break;
         case LGICP_INIT_CANDIDATE: {
           const hm::Pose p1 = hm::pose_from_quat(c.pose_from_q, c.pose_from_t);

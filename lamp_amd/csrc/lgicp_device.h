@@ -124,4 +124,8 @@ hipError_t launch_cov_knn(const float4* xyz, int n, int n_pad, int k, double eps
 hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float4* keys, int n_key,
                        float r2, unsigned char* need, float* spfh, float* out, hipStream_t stream);
 
+// Harris3D response + non-maxima suppression (radius^2 = r2); response[n], is_key[n]
+hipError_t launch_harris(const float4* xyz, const float4* nrm, int n, float r2, float threshold,
+                         float* response, unsigned char* is_key, hipStream_t stream);
+
 }  // namespace lgicp

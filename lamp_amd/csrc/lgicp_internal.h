@@ -84,6 +84,18 @@ struct lgicp_ctx {
 
 namespace lgicp_detail {
 
+// Harris keypoints + FPFH descriptors of one device-resident cloud (the feature front end of
+// GetSacInitialAlignment, IcpLoopComputation.cc:654-682)
+struct CloudFeatures {
+  std::vector<int> idx;       // keypoint indices, ascending
+  std::vector<float> xyz;     // [k][3]
+  std::vector<float> feat;    // [k][33]
+};
+int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
+                           CloudFeatures* out);
+int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
+                     const float guess[16], uint32_t seed, float T_out[16], double* score);
+
 inline int fail(lgicp_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;

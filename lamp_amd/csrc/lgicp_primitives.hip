@@ -236,4 +236,97 @@ int lgicp_fpfh(lgicp_ctx* ctx, const float* surface_xyz, const float* surface_no
   return LGICP_OK;
 }
 
+int lgicp_harris_keypoints(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
+                           int32_t* idx_out, size_t capacity, size_t* count) {
+  if (!ctx || !count || (n && (!xyz || !normals)) || (capacity && !idx_out))
+    return fail(ctx, LGICP_E_INVALID, "null argument");
+  *count = 0;
+  if (n == 0) return LGICP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  Dev d;
+  float4* d_x = upload_points(d, xyz, n, (int)n, 1.f);
+  float4* d_n = upload_points(d, normals, n, (int)n, 0.f);
+  if (!d_x || !d_n) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  CloudFeatures cf;
+  const int rc = compute_cloud_features(ctx, d_x, d_n, (int)n, &cf);
+  if (rc != LGICP_OK) return rc;
+  *count = cf.idx.size();
+  for (size_t i = 0; i < cf.idx.size() && i < capacity; ++i) idx_out[i] = cf.idx[i];
+  return LGICP_OK;
+}
+
+int lgicp_sac_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const float* src_normals,
+                                size_t n_src, const float* tgt_xyz, const float* tgt_normals,
+                                size_t n_tgt, const float guess[16], float T_out[16],
+                                double* fitness_score) {
+  if (!ctx || !guess || !T_out || !fitness_score || !src_xyz || !src_normals || !tgt_xyz ||
+      !tgt_normals)
+    return fail(ctx, LGICP_E_INVALID, "null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  Dev d;
+  float4* d_sx = upload_points(d, src_xyz, n_src, (int)std::max<size_t>(n_src, 1), 1.f);
+  float4* d_sn = upload_points(d, src_normals, n_src, (int)std::max<size_t>(n_src, 1), 0.f);
+  float4* d_tx = upload_points(d, tgt_xyz, n_tgt, (int)std::max<size_t>(n_tgt, 1), 1.f);
+  float4* d_tn = upload_points(d, tgt_normals, n_tgt, (int)std::max<size_t>(n_tgt, 1), 0.f);
+  if (!d_sx || !d_sn || !d_tx || !d_tn) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  CloudFeatures fs, ft;
+  int rc = compute_cloud_features(ctx, d_sx, d_sn, (int)n_src, &fs);
+  if (rc == LGICP_OK) rc = compute_cloud_features(ctx, d_tx, d_tn, (int)n_tgt, &ft);
+  if (rc != LGICP_OK) return rc;
+  return sac_align_device(ctx, fs, ft, guess, 0x5AC1A000u, T_out, fitness_score);
+}
+
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+namespace lgicp_detail {
+
+int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
+                           CloudFeatures* out) {
+  out->idx.clear();
+  out->xyz.clear();
+  out->feat.clear();
+  if (n <= 0) return LGICP_OK;
+  const lgicp_config& cfg = ctx->cfg;
+  if (cfg.harris_response != 1 || cfg.harris_refine || !cfg.harris_suppression)
+    return fail(ctx, LGICP_E_UNSUPPORTED,
+                "only the HARRIS response with non-maxima suppression and no refinement is built");
+  hipStream_t st = ctx->stream;
+  Dev d;
+  float* d_resp = d.alloc<float>((size_t)n);
+  unsigned char* d_key = d.alloc<unsigned char>((size_t)n);
+  if (!d_resp || !d_key) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  const float hr2 = (float)(cfg.harris_radius * cfg.harris_radius);
+  HIP_TRY(ctx, launch_harris(d_xyz, d_nrm, n, hr2, (float)cfg.harris_threshold, d_resp, d_key, st));
+  std::vector<unsigned char> flags((size_t)n);
+  std::vector<float4> pts((size_t)n);
+  HIP_TRY(ctx, hipMemcpyAsync(flags.data(), d_key, (size_t)n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i)
+    if (flags[i]) out->idx.push_back(i);
+  const size_t k = out->idx.size();
+  if (k == 0) return LGICP_OK;
+  // keypoint coordinates: gather on the host from one download of the cloud
+  HIP_TRY(ctx, hipMemcpy(pts.data(), d_xyz, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+  std::vector<float4> kp(k);
+  out->xyz.resize(3 * k);
+  for (size_t q = 0; q < k; ++q) {
+    kp[q] = pts[out->idx[q]];
+    out->xyz[3 * q] = kp[q].x, out->xyz[3 * q + 1] = kp[q].y, out->xyz[3 * q + 2] = kp[q].z;
+  }
+  float4* d_kp = d.alloc<float4>(k);
+  unsigned char* d_need = d.alloc<unsigned char>((size_t)n);
+  float* d_spfh = d.alloc<float>((size_t)n * 33);
+  float* d_out = d.alloc<float>(k * 33);
+  if (!d_kp || !d_need || !d_spfh || !d_out) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp.data(), sizeof(float4) * k, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(d_spfh, 0, sizeof(float) * (size_t)n * 33, st));
+  const float fr2 = (float)(cfg.sac_features_radius * cfg.sac_features_radius);
+  HIP_TRY(ctx, launch_fpfh(d_xyz, d_nrm, n, d_kp, (int)k, fr2, d_need, d_spfh, d_out, st));
+  out->feat.resize(33 * k);
+  HIP_TRY(ctx, hipMemcpyAsync(out->feat.data(), d_out, sizeof(float) * 33 * k, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return LGICP_OK;
+}
+
+}  // namespace lgicp_detail

@@ -33,6 +33,12 @@ class GpuIcpLoopComputation : public LoopComputation {
                         const geometry_msgs::Pose& pose2, Transform3* delta, double covariance[36],
                         double* fitness_score);
 
+  // IcpLoopComputation::GetSacInitialAlignment (IcpLoopComputation.h:110-113): *tf_out is the
+  // guess on entry (row-major 4x4) and the SAC-IA transform on return
+  void GetSacInitialAlignment(const pose_graph_msgs::PointCloud& source,
+                              const pose_graph_msgs::PointCloud& target, float tf_out[16],
+                              double& sac_fitness_score);
+
   bool CheckReclosingDistance(uint64_t key_from, uint64_t key_to) const;
 
   // seconds; tests replace it (the reference calls ros::Time::now())

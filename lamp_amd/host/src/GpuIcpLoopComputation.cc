@@ -107,6 +107,27 @@ void GpuIcpLoopComputation::KeyedPoseCallback(const pose_graph_msgs::PoseGraph& 
   }
 }
 
+// IcpLoopComputation::GetSacInitialAlignment (IcpLoopComputation.cc:650-705)
+void GpuIcpLoopComputation::GetSacInitialAlignment(const pose_graph_msgs::PointCloud& source,
+                                                   const pose_graph_msgs::PointCloud& target,
+                                                   float tf_out[16],
+                                                   double& sac_fitness_score) {
+  auto split = [](const pose_graph_msgs::PointCloud& c, std::vector<float>& xyz, std::vector<float>& nrm) {
+    xyz.resize(c.size() * 3), nrm.resize(c.size() * 3);
+    for (size_t i = 0; i < c.size(); ++i) {
+      xyz[3 * i] = c[i].x, xyz[3 * i + 1] = c[i].y, xyz[3 * i + 2] = c[i].z;
+      nrm[3 * i] = c[i].normal_x, nrm[3 * i + 1] = c[i].normal_y, nrm[3 * i + 2] = c[i].normal_z;
+    }
+  };
+  std::vector<float> sx, sn, tx, tn;
+  split(source, sx, sn);
+  split(target, tx, tn);
+  float T[16];
+  if (lgicp_sac_initial_alignment(ctx_, sx.data(), sn.data(), source.size(), tx.data(), tn.data(),
+                                  target.size(), tf_out, T, &sac_fitness_score) == LGICP_OK)
+    std::memcpy(tf_out, T, sizeof(T));
+}
+
 // IcpLoopComputation::CheckReclosingDistance (IcpLoopComputation.cc:205-240): a pair is
 // skipped when both of its keys lie within dist_before_reclosing_ of an already closed key.
 // The reference dereferences std::prev(begin()) when the key precedes every closed key; the

@@ -131,6 +131,34 @@ static void OnDevice() {
     std::printf("{\"perform_alignment_t\": [%.6f, %.6f, %.6f], \"fitness\": %.3g, ",
                 tf.translation[0], tf.translation[1], tf.translation[2], fit);
   }
+  {  // TestLoopComputation.TestSacInitialAlign and PerformAlignment with the default FEATURES init
+    ParameterServer def = ParameterServer::ReferenceDefaults();
+    NodeHandle nhd{"base", &def};
+    Probe icp;
+    CHECK(icp.Initialize(nhd));
+    PointCloud corner = Corner(), moved = Shift(corner, 1.f, -0.001f);
+    float T_est[16];
+    for (int i = 0; i < 16; ++i) T_est[i] = (i % 5 == 0) ? 1.f : 0.f;
+    double fitness_score = -1;
+    icp.GetSacInitialAlignment(corner, moved, T_est, fitness_score);
+    CHECK(std::fabs(T_est[3] - 1.f) < 1e-6 && std::fabs(T_est[7] + 0.001f) < 1e-7 && T_est[11] == 0.f);
+    CHECK(T_est[0] == 1.f && T_est[5] == 1.f && T_est[10] == 1.f && T_est[1] == 0.f);
+    CHECK(fitness_score == 0.0);
+    icp.KeyedScanCallback({0, corner});
+    icp.KeyedScanCallback({100, moved});
+    pose_graph_msgs::PoseGraph kp;
+    pose_graph_msgs::PoseGraphNode kp0, kp100;
+    kp0.key = 0, kp100.key = 100;
+    kp0.pose.position.z = 0.1;
+    kp100.pose.position.x = -0.9, kp100.pose.position.y = 0.1;
+    kp.nodes = {kp0, kp100};
+    icp.KeyedPoseCallback(kp);
+    Transform3 tf;
+    double cov[36], fit = -1;
+    CHECK(icp.PerformAlignment(100, 0, kp100.pose, kp0.pose, &tf, cov, &fit));
+    CHECK(std::fabs(tf.translation[0] - 1) < 1e-3 && std::fabs(tf.translation[1] + 0.001) < 1e-3 &&
+          std::fabs(tf.translation[2]) < 1e-3);
+  }
   {  // TestICPComputation.TestThreadedEqualsNonThreaded, device batch instead of the pool
     ps.Set("base/icp_lc/iterations", 100);
     Probe icp;

@@ -132,6 +132,19 @@ void lo_icp_observability(const float* xyz, const float* normals, int n, double 
 void lo_fpfh(const float* surface_xyz, const float* surface_normals, int n,
              const float* keypoints_xyz, int n_key, double radius, float* out);
 
+/* ------------------------------------------------------------------ Harris3D + SAC-IA */
+/* pcl::HarrisKeypoint3D (HARRIS response) as configured by lamp_utils::ComputeKeypoints
+ * (PointCloudUtils.cc:78-96) */
+void lo_harris_response(const float* xyz, const float* normals, int n, double radius,
+                        float* response);
+int lo_harris_keypoints(const float* xyz, const float* normals, int n, double radius,
+                        double threshold, int nms, int32_t* out_idx, float* out_response);
+/* pcl::SampleConsensusInitialAlignment as driven by GetSacInitialAlignment
+ * (IcpLoopComputation.cc:650-705); returns getFitnessScore() */
+double lo_sac_ia(const float* src_kp, const float* src_feat, int n_src, const float* tgt_kp,
+                 const float* tgt_feat, int n_tgt, int max_iterations, int k_corr,
+                 const float guess[16], uint32_t seed, float T_out[16]);
+
 /* ------------------------------------------------------------------ IcpLoopComputation */
 /* IcpLoopComputation.cc:707-768 */
 void lo_icp_cov_point_plane(const float* scan1_xyz, int n1, const float* scan2_normals, int n2,

@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "liblamp_oracle.so")
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds)."""
-    srcs = ["lo_linalg.c", "lo_kdtree.c", "lo_gicp.c", "lo_icp_loop.c", "lo_fpfh.c", "lamp_oracle.h"]
+    srcs = ["lo_linalg.c", "lo_kdtree.c", "lo_gicp.c", "lo_icp_loop.c", "lo_fpfh.c", "lo_features.c", "lamp_oracle.h"]
     if not force and os.path.exists(_LIB_PATH):
         newest = max(os.path.getmtime(os.path.join(_HERE, s)) for s in srcs)
         if os.path.getmtime(_LIB_PATH) >= newest:
@@ -72,6 +72,7 @@ def lib():
         _lib.lo_fitness_score.restype = C.c_double
         _lib.lo_mat6_det.restype = C.c_double
         _lib.lo_kdtree_build.restype = C.c_void_p
+        _lib.lo_sac_ia.restype = C.c_double
     return _lib
 
 
@@ -275,6 +276,47 @@ def fpfh(surface_xyz, surface_normals, keypoints_xyz, radius):
     lib().lo_fpfh(_p(sx, C.c_float), _p(sn, C.c_float), len(sx), _p(kx, C.c_float), len(kx),
                   C.c_double(radius), _p(out, C.c_float))
     return out
+
+
+def harris_keypoints(xyz, normals, radius, threshold=5e-9, nms=True):
+    xyz, normals = _f32(xyz), _f32(normals)
+    idx = np.empty(len(xyz), np.int32)
+    resp = np.empty(len(xyz), np.float32)
+    k = lib().lo_harris_keypoints(_p(xyz, C.c_float), _p(normals, C.c_float), len(xyz),
+                                  C.c_double(radius), C.c_double(threshold), int(nms),
+                                  _p(idx, C.c_int32), _p(resp, C.c_float))
+    return idx[:k].copy(), resp[:k].copy()
+
+
+def harris_response(xyz, normals, radius):
+    xyz, normals = _f32(xyz), _f32(normals)
+    resp = np.empty(len(xyz), np.float32)
+    lib().lo_harris_response(_p(xyz, C.c_float), _p(normals, C.c_float), len(xyz),
+                             C.c_double(radius), _p(resp, C.c_float))
+    return resp
+
+
+def sac_ia(src_kp, src_feat, tgt_kp, tgt_feat, max_iterations, k_corr=5, guess=None, seed=12345):
+    sk, sf, tk, tf = _f32(src_kp), _f32(src_feat), _f32(tgt_kp), _f32(tgt_feat)
+    g = _f32(np.eye(4) if guess is None else guess).reshape(16)
+    T = np.empty(16, np.float32)
+    fit = lib().lo_sac_ia(_p(sk, C.c_float), _p(sf, C.c_float), len(sk), _p(tk, C.c_float),
+                          _p(tf, C.c_float), len(tk), max_iterations, k_corr, _p(g, C.c_float),
+                          C.c_uint32(seed), _p(T, C.c_float))
+    return T.reshape(4, 4), fit
+
+
+def sac_initial_alignment(src, src_n, tgt, tgt_n, harris_radius=0.1, harris_threshold=5e-9,
+                          features_radius=2.0, iterations=500, guess=None, seed=0x5AC1A000):
+    """GetSacInitialAlignment (IcpLoopComputation.cc:650-705): Harris keypoints, FPFH at the
+    keypoints over the full cloud, SAC-IA.  Returns T, fitness, (source, target) keypoint ids."""
+    src, tgt = _f32(src), _f32(tgt)
+    i, _ = harris_keypoints(src, src_n, harris_radius, harris_threshold)
+    j, _ = harris_keypoints(tgt, tgt_n, harris_radius, harris_threshold)
+    fs = fpfh(src, src_n, src[i], features_radius)
+    ft = fpfh(tgt, tgt_n, tgt[j], features_radius)
+    T, fit = sac_ia(src[i], fs, tgt[j], ft, iterations, 5, guess, seed)
+    return T, fit, (i, j)
 
 
 def pose_from_quat(q_wxyz, t):

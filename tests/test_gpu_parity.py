@@ -327,3 +327,109 @@ def test_fpfh_matches_oracle(ctx):
     # a keypoint far from everything has an all-zero descriptor
     far = ctx.fpfh(xyz, nrm, np.array([[100.0, 100.0, 100.0]]), 2.0)
     assert np.all(far == 0)
+
+
+# ------------------------------------------------------------------ K5/K6: Harris keypoints, SAC-IA
+def test_harris_keypoints_match_oracle():
+    """lamp_utils::ComputeKeypoints (PointCloudUtils.cc:71-96): keypoint indices are index work,
+    compared exactly."""
+    from lamp_amd import capi
+    c = capi.Context(harris_radius=1.0)
+    try:
+        corner, cn = F.generate_corner()
+        assert list(c.harris_keypoints(corner, cn)) == [0, 100, 200]
+        plane, pn = F.generate_plane()
+        assert len(c.harris_keypoints(plane, pn)) == 0
+    finally:
+        c.close()
+    for radius, n, seed in [(0.1, 4000, 40), (0.3, 4000, 41), (0.5, 7000, 42)]:
+        c = capi.Context(harris_radius=radius)
+        try:
+            src, sn, tgt, tn, _ = F.make_pair(n, seed)
+            for xyz, nrm in ((src, sn), (tgt, tn)):
+                ref, _ = O.harris_keypoints(xyz, nrm, radius)
+                got = c.harris_keypoints(xyz, nrm)
+                assert np.array_equal(got, ref), (radius, len(got), len(ref))
+        finally:
+            c.close()
+
+
+def test_sac_initial_alignment_reference_corner_case():
+    """TestSacInitialAlign (test_loop_computation.cc:78-104) through the C ABI."""
+    from lamp_amd import capi
+    c = capi.Context()                                   # base-station parameter block
+    try:
+        corner, cn = F.generate_corner()
+        moved, mn, T = F.shifted_corner()
+        T_est, fit = c.sac_initial_alignment(corner, cn, moved, mn)
+        assert np.allclose(T_est, T, rtol=1e-5, atol=1e-7)      # Eigen isApprox-like
+        assert fit == 0.0
+        plane, pn = F.generate_plane()
+        T_est, fit = c.sac_initial_alignment(plane, pn, plane, pn)
+        assert np.array_equal(T_est, np.eye(4, dtype=np.float32)) and fit > 1e300
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("seed,radius", [(40, 0.3), (43, 0.5)])
+def test_sac_initial_alignment_matches_oracle(seed, radius):
+    """Same keypoints, descriptors, sampling sequence and scoring as the CPU restatement: the
+    chosen hypothesis is the same one (parity unpinned against PCL, whose sampling uses rand())."""
+    from lamp_amd import capi
+    c = capi.Context(harris_radius=radius, sac_iterations=300)
+    try:
+        src, sn, tgt, tn, _ = F.make_pair(4000, seed, rot_deg=3.0, trans=0.3)
+        g = np.eye(4, dtype=np.float32); g[0, 3] = 0.1
+        for guess in (None, g):
+            T_ref, fit_ref, (i, j) = O.sac_initial_alignment(src, sn, tgt, tn, harris_radius=radius,
+                                                            iterations=300, guess=guess)
+            assert len(i) >= 3 and len(j) >= 1
+            T_est, fit = c.sac_initial_alignment(src, sn, tgt, tn, guess)
+            assert np.allclose(T_est, T_ref, atol=1e-5), (T_est, T_ref)
+            assert abs(fit - fit_ref) <= 1e-5 * fit_ref
+    finally:
+        c.close()
+
+
+def test_submit_features_init_matches_oracle():
+    """init_method FEATURES (IcpLoopComputation.cc:517-527): SAC-IA from the odometry guess, then
+    GICP from the SAC transform; a keypoint fitness at or above the threshold drops the pair."""
+    from lamp_amd import capi
+    radius = 0.3
+    c = capi.Context(init_method=capi.INIT_FEATURES, harris_radius=radius, sac_iterations=100,
+                     transform_thresholding=0)
+    try:
+        cases = []
+        for i in range(3):
+            src, sn, tgt, tn, T = F.make_pair(4000 + 500 * i, 60 + i, rot_deg=2.0, trans=0.2)
+            k_to, k_from = 100 + 10 * i, 900 + 10 * i
+            _register(c, k_to, tgt, tn)
+            _register(c, k_from, src, sn, t=(0.05, 0.0, 0.0))
+            cases.append((k_from, k_to, src, sn, tgt, tn))
+        res = c.submit([(k[0], k[1]) for k in cases])
+        g = np.eye(4, dtype=np.float32); g[0, 3] = 0.05
+        for r, (k_from, k_to, src, sn, tgt, tn) in zip(res, cases):
+            d = capi.result_to_dict(r)
+            T0, fit0, _ = O.sac_initial_alignment(src, sn, tgt, tn, harris_radius=radius,
+                                                  iterations=100, guess=g,
+                                                  seed=capi.pair_seed(k_from, k_to))
+            assert np.allclose(d["T_init"], T0, atol=1e-5)
+            assert abs(d["init_fitness"] - fit0) <= 1e-5 * fit0
+            assert fit0 < 32.0
+            ref = O.gicp_align(O.base_gicp_params(solver=O.SOLVER_GN), src, sn, tgt, tn, guess=T0)
+            assert d["converged"] == ref["converged"]
+            ang, te = _rot_err(ref["T"], d["T_icp"])
+            assert ang < 1e-4 and te < 1e-4
+    finally:
+        c.close()
+    # threshold below every achievable score: all pairs are dropped at the initialisation
+    c = capi.Context(init_method=capi.INIT_FEATURES, harris_radius=radius, sac_iterations=20,
+                     sac_fitness_score_threshold=1e-12)
+    try:
+        k_from, k_to, src, sn, tgt, tn = cases[0]
+        _register(c, k_to, tgt, tn)
+        _register(c, k_from, src, sn)
+        r = c.submit([(k_from, k_to)])[0]
+        assert r.status == capi.PAIR_INIT_REJECTED and r.iterations == 0
+    finally:
+        c.close()

@@ -246,3 +246,39 @@ def test_fpfh_oracle_properties():
     f2 = O.fpfh(x2, n2, x2[::300], 2.0)
     # axis-aligned room normals put f1 exactly on +-pi, whose sign flips under rounding
     assert np.abs(f - f2).max() < 6.0 and np.median(np.abs(f - f2)) < 1e-3
+
+
+# ------------------------------------------------------------------ Harris keypoints, SAC-IA
+def test_harris_corner_keypoints():
+    """lamp_utils::ComputeKeypoints (PointCloudUtils.cc:71-96).  On the three-plane corner the
+    only points whose neighbourhood holds all three normals equally are the three copies of the
+    origin; their response is 0.04 + det(I/3) - 0.04 = 1/27."""
+    corner, cn = F.generate_corner()
+    idx, resp = O.harris_keypoints(corner, cn, 1.0)
+    assert list(idx) == [0, 100, 200]
+    assert np.all(corner[idx] == 0)
+    assert np.allclose(resp, 1 / 27, rtol=1e-5)
+    # a single plane has a rank-1 normal covariance: response 0 everywhere, no keypoint
+    plane, pn = F.generate_plane()
+    assert np.all(O.harris_response(plane, pn, 1.0) == 0)
+    assert len(O.harris_keypoints(plane, pn, 1.0)[0]) == 0
+
+
+def test_sac_ia_reference_corner_case():
+    """TestSacInitialAlign (test_loop_computation.cc:78-104): corner vs the same corner moved by
+    (1, -0.001, 0) is expected to give exactly that translation, identity rotation.  All three
+    keypoints sit on the origin, so every sample triple is degenerate and the estimate is the
+    centroid shift."""
+    corner, cn = F.generate_corner()
+    moved, mn, _ = F.shifted_corner()
+    T, fit, (i, j) = O.sac_initial_alignment(corner, cn, moved, mn, iterations=500)
+    assert len(i) == 3 and len(j) == 3
+    assert np.array_equal(T[:3, :3], np.eye(3, dtype=np.float32))
+    assert np.allclose(T[:3, 3], [1.0, -0.001, 0.0], atol=1e-7)
+    assert fit == 0.0
+
+
+def test_sac_ia_too_few_keypoints():
+    plane, pn = F.generate_plane()
+    T, fit, _ = O.sac_initial_alignment(plane, pn, plane, pn, iterations=10)
+    assert np.array_equal(T, np.eye(4, dtype=np.float32)) and fit > 1e300
