@@ -133,7 +133,9 @@ typedef struct lgicp_result {
   double information[36];     /* Ap of ComputeAp_ForPoint2PlaneICP / 0.05^2 (POINT2PLANE) or
                                  inverse of covariance otherwise; zero when not computed */
   float T_init[16];           /* the guess handed to GICP (after SAC-IA when init is FEATURES) */
-  double init_fitness;        /* sac_ia.getFitnessScore() (IcpLoopComputation.cc:701); 0 otherwise */
+  double init_fitness;        /* FEATURES: sac_ia.getFitnessScore() (IcpLoopComputation.cc:701);
+                                 TEASERPP: size of the inlier clique when the TEASER++ transform
+                                 replaced the odometry guess, else 0; other methods: 0 */
 } lgicp_result;
 
 typedef struct lgicp_stats {
@@ -213,13 +215,25 @@ int lgicp_harris_keypoints(lgicp_ctx* ctx, const float* xyz, const float* normal
                            int32_t* idx_out, size_t capacity, size_t* count);
 /* IcpLoopComputation::GetSacInitialAlignment (IcpLoopComputation.cc:650-705): Harris keypoints
  * and FPFH descriptors of both clouds on the device, SAC-IA (sac_iterations, 5 candidate
- * correspondences) on the host.  guess is scored as the first hypothesis when it is not the
+ * correspondences; hypotheses drawn on the host, scored on the device).  guess is scored as the first hypothesis when it is not the
  * identity.  fitness_score = getFitnessScore() of the keypoint alignment (DBL_MAX when a cloud
  * yields fewer than 3 / 1 keypoints). */
 int lgicp_sac_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const float* src_normals,
                                 size_t n_src, const float* tgt_xyz, const float* tgt_normals,
                                 size_t n_tgt, const float guess[16], float T_out[16],
                                 double* fitness_score);
+
+/* IcpLoopComputation::GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081): the same
+ * keypoint/descriptor front end, every source descriptor matched with its 5 nearest target
+ * descriptors, TEASER++ (noise bound 0.5, GNC-TLS rotation, greedy max-clique inlier selection)
+ * on the matches.  T_out is the guess unless there are more than 10 matches and the TEASER++
+ * transform's truncated error over them is not larger than the guess's; *used_teaser tells
+ * which.  n_matches / n_clique (may be NULL) report the sizes of the match set and of the
+ * inlier clique. */
+int lgicp_teaser_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const float* src_normals,
+                                   size_t n_src, const float* tgt_xyz, const float* tgt_normals,
+                                   size_t n_tgt, const float guess[16], float T_out[16],
+                                   int32_t* used_teaser, int32_t* n_matches, int32_t* n_clique);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,8 @@ EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_
            "lgicp_add_keyframe", "lgicp_add_pose", "lgicp_has_keyframe", "lgicp_has_pose",
            "lgicp_submit", "lgicp_get_stats", "lgicp_nn_search", "lgicp_covariances_from_normals",
            "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh",
-           "lgicp_harris_keypoints", "lgicp_sac_initial_alignment"]
+           "lgicp_harris_keypoints", "lgicp_sac_initial_alignment",
+           "lgicp_teaser_initial_alignment"]
 
 
 class Config(C.Structure):
@@ -108,6 +109,10 @@ def lib():
         L.lgicp_sac_initial_alignment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                                   C.c_void_p, C.POINTER(C.c_double)]
+        L.lgicp_teaser_initial_alignment.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+            C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+            C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -252,6 +257,16 @@ class Context:
                                                       _ptr(a[2]), _ptr(a[3]), len(a[2]), _ptr(g),
                                                       _ptr(T), C.byref(fit)))
         return T.reshape(4, 4), fit.value
+
+    def teaser_initial_alignment(self, src, src_n, tgt, tgt_n, guess=None):
+        a = [_f32(v).reshape(-1, 3) for v in (src, src_n, tgt, tgt_n)]
+        g = _f32(np.eye(4) if guess is None else guess).reshape(16)
+        T = np.empty(16, np.float32)
+        used, nm, nc = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(lib().lgicp_teaser_initial_alignment(
+            self._h, _ptr(a[0]), _ptr(a[1]), len(a[0]), _ptr(a[2]), _ptr(a[3]), len(a[2]), _ptr(g),
+            _ptr(T), C.byref(used), C.byref(nm), C.byref(nc)))
+        return T.reshape(4, 4), bool(used.value), nm.value, nc.value
 
     def compute_ap(self, query, ref_normals, corr, T, normalize=True):
         q, rn = _f32(query).reshape(-1, 3), _f32(ref_normals).reshape(-1, 3)

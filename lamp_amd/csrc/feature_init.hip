@@ -14,6 +14,7 @@
 
 #include "lgicp_internal.h"
 #include "sac_ia.h"
+#include "teaser.h"
 
 namespace lgicp {
 
@@ -103,6 +104,34 @@ __global__ __launch_bounds__(256) void sac_score_kernel(const float* __restrict_
   }
 }
 
+// Scale-consistency graph of n matches (TEASER++'s inlier graph when no scale is estimated):
+// bit j of row i is set when | |s_j - s_i| - |d_j - d_i| | <= beta.  One lane per 64-bit word.
+__global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __restrict__ src,
+                                                                const double* __restrict__ dst,
+                                                                int n, int words, double beta,
+                                                                unsigned long long* __restrict__ bits) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)n * words) return;
+  const int i = (int)(gid / words), w = (int)(gid % words);
+  const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+  const double dx = dst[3 * i], dy = dst[3 * i + 1], dz = dst[3 * i + 2];
+  unsigned long long m = 0;
+  for (int b = 0; b < 64; ++b) {
+    const int j = w * 64 + b;
+    if (j >= n) break;
+    if (j == i) continue;
+    double e, a = 0, c = 0;
+    e = src[3 * j] - sx, a += e * e;
+    e = src[3 * j + 1] - sy, a += e * e;
+    e = src[3 * j + 2] - sz, a += e * e;
+    e = dst[3 * j] - dx, c += e * e;
+    e = dst[3 * j + 1] - dy, c += e * e;
+    e = dst[3 * j + 2] - dz, c += e * e;
+    if (fabs(sqrt(a) - sqrt(c)) <= beta) m |= 1ull << b;
+  }
+  bits[gid] = m;
+}
+
 }  // namespace lgicp
 
 namespace lgicp_detail {
@@ -174,6 +203,98 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
     if ((float)ef[2 * h] < lowest) lowest = (float)ef[2 * h], best = h;
   std::memcpy(T_out, &hyp.T[(size_t)16 * best], sizeof(float) * 16);
   *score = ef[2 * best + 1] / n_src;
+  return LGICP_OK;
+}
+
+// descriptor k-NN table [n_src][k] on the device
+static int feature_knn_table(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
+                             int k, std::vector<int>* nn) {
+  const int n_src = (int)src.idx.size(), n_tgt = (int)tgt.idx.size();
+  hipStream_t st = ctx->stream;
+  Scratch d;
+  float* d_sf = d.alloc<float>(src.feat.size());
+  float* d_tf = d.alloc<float>(tgt.feat.size());
+  int* d_nn = d.alloc<int>((size_t)n_src * k);
+  if (!d_sf || !d_tf || !d_nn) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, hipMemcpyAsync(d_sf, src.feat.data(), sizeof(float) * src.feat.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_tf, tgt.feat.data(), sizeof(float) * tgt.feat.size(), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lgicp::feature_knn_kernel, dim3((n_src + 127) / 128), dim3(128), 0, st, d_sf,
+                     n_src, d_tf, n_tgt, k, d_nn);
+  HIP_TRY(ctx, hipGetLastError());
+  nn->resize((size_t)n_src * k);
+  HIP_TRY(ctx, hipMemcpyAsync(nn->data(), d_nn, sizeof(int) * nn->size(), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return LGICP_OK;
+}
+
+// GetTeaserInitialAlignment from the keypoints on (IcpLoopComputation.cc:990-1081).  T_out is
+// the guess unless the TEASER++ transform scores at least as well over the matches.
+int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
+                        const float guess[16], float T_out[16], int* used, int* n_matches,
+                        int* n_clique) {
+  namespace tz = lgicp::teaser;
+  std::memcpy(T_out, guess, sizeof(float) * 16);
+  *used = *n_matches = *n_clique = 0;
+  const int n_src = (int)src.idx.size(), n_tgt = (int)tgt.idx.size();
+  if (n_src == 0 || n_tgt == 0) return LGICP_OK;
+  const int k = std::min(5, n_tgt);  // calculateKCorrespondences(..., 5), IcpLoopComputation.cc:997
+  std::vector<int> nn;
+  int rc = feature_knn_table(ctx, src, tgt, k, &nn);
+  if (rc != LGICP_OK) return rc;
+  const int n = n_src * k;
+  *n_matches = n;
+  if (n <= 10) return LGICP_OK;  // IcpLoopComputation.cc:1002
+  if (n > 24576)
+    return fail(ctx, LGICP_E_UNSUPPORTED,
+                "TEASER++ initialisation: %d descriptor matches exceed the 24576 the consistency "
+                "graph is sized for (raise harris_threshold or harris_radius)", n);
+  std::vector<double> s((size_t)3 * n), d((size_t)3 * n);
+  for (int i = 0; i < n_src; ++i)
+    for (int q = 0; q < k; ++q)
+      for (int c = 0; c < 3; ++c) {
+        s[3 * ((size_t)i * k + q) + c] = (double)src.xyz[3 * i + c];
+        d[3 * ((size_t)i * k + q) + c] = (double)tgt.xyz[3 * nn[(size_t)i * k + q] + c];
+      }
+  tz::Params prm;
+  tz::BitGraph g;
+  g.n = n;
+  g.words = (n + 63) / 64;
+  g.bits.resize((size_t)n * g.words);
+  {
+    hipStream_t st = ctx->stream;
+    Scratch dev;
+    double* d_s = dev.alloc<double>(s.size());
+    double* d_d = dev.alloc<double>(d.size());
+    unsigned long long* d_bits = dev.alloc<unsigned long long>(g.bits.size());
+    if (!d_s || !d_d || !d_bits) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+    HIP_TRY(ctx, hipMemcpyAsync(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_d, d.data(), sizeof(double) * d.size(), hipMemcpyHostToDevice, st));
+    const long long total = (long long)n * g.words;
+    hipLaunchKernelGGL(lgicp::consistency_graph_kernel, dim3((unsigned)((total + 255) / 256)),
+                       dim3(256), 0, st, d_s, d_d, n, g.words,
+                       2.0 * prm.noise_bound * std::sqrt(prm.cbar2), d_bits);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(g.bits.data(), d_bits, sizeof(uint64_t) * g.bits.size(),
+                                hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
+  const tz::Solution sol = tz::solve_on_clique(s, d, tz::greedy_clique(g), prm);
+  *n_clique = (int)sol.clique.size();
+  double Ro[9], to[3];
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) Ro[a * 3 + b] = (double)guess[a * 4 + b];
+    to[a] = (double)guess[a * 4 + 3];
+  }
+  const double e_teaser = tz::error_metric(s, d, sol.R, sol.t, 100.0);
+  const double e_odom = tz::error_metric(s, d, Ro, to, 100.0);
+  if (e_teaser <= e_odom) {  // IcpLoopComputation.cc:1065-1068
+    for (int i = 0; i < 16; ++i) T_out[i] = (i == 15) ? 1.f : 0.f;
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) T_out[a * 4 + b] = (float)sol.R[a * 3 + b];
+      T_out[a * 4 + 3] = (float)sol.t[a];
+    }
+    *used = 1;
+  }
   return LGICP_OK;
 }
 

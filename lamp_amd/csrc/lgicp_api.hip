@@ -477,12 +477,12 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   HIP_TRY(ctx, launch_normalize_constants(ctx->d_clouds.p, ctx->d_ints.p + off_ids,
                                           (int)scan1_ids.size(), st));
 
-  // ---- FEATURES initialisation (IcpLoopComputation.cc:517-527, 650-705) ----------------------
-  // Harris keypoints and FPFH descriptors once per distinct cloud of the batch, SAC-IA per
-  // pair starting from the odometry guess; a pair whose keypoint fitness reaches the
-  // threshold is dropped before GICP.
+  // ---- FEATURES / TEASERPP initialisation (IcpLoopComputation.cc:517-531, 650-705, 949-1081) --
+  // Harris keypoints and FPFH descriptors once per distinct cloud of the batch, SAC-IA or
+  // TEASER++ per pair starting from the odometry guess; with SAC-IA a pair whose keypoint
+  // fitness reaches the threshold is dropped before GICP.
   std::vector<char> init_rejected((size_t)n_pairs, 0);
-  if (cfg.init_method == LGICP_INIT_FEATURES) {
+  if (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP) {
     std::map<int, CloudFeatures> feats;
     for (int p = 0; p < n_pairs; ++p)
       for (int c : {bp.pairs[p].src_cloud, bp.pairs[p].tgt_cloud})
@@ -494,6 +494,18 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
     for (int p = 0; p < n_pairs; ++p) {
       const PairPlan& pp = bp.pairs[p];
       float T0[16];
+      if (cfg.init_method == LGICP_INIT_TEASERPP) {
+        // IcpLoopComputation.cc:528-531: never rejects; keeps the odometry guess unless the
+        // TEASER++ transform explains the descriptor matches at least as well
+        int used = 0, nm = 0, nc = 0;
+        const int rc = teaser_align_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], pp.guess,
+                                           T0, &used, &nm, &nc);
+        if (rc != LGICP_OK) return rc;
+        out[pp.cand].init_fitness = used ? (double)nc : 0.0;
+        std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
+        if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
+        continue;
+      }
       double score = 0;
       // one fixed sampling sequence per (key_from, key_to): results do not depend on how the
       // candidates were batched
@@ -722,11 +734,6 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   if (!ctx) return LGICP_E_INVALID;
   if (n && (!cand || !out)) return fail(ctx, LGICP_E_INVALID, "null argument");
   const lgicp_config& cfg = ctx->cfg;
-  if (cfg.init_method == LGICP_INIT_TEASERPP)
-    return fail(ctx, LGICP_E_UNSUPPORTED,
-                "init_method %d (TEASER++ initial alignment) is not available on the device "
-                "path yet",
-                cfg.init_method);
   HIP_TRY(ctx, hipSetDevice(cfg.device));
   ctx->stats.nn_ms = ctx->stats.reduce_ms = ctx->stats.solve_ms = ctx->stats.cov_ms =
       ctx->stats.post_ms = ctx->stats.total_ms = 0;
@@ -770,7 +777,8 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
       pp.pose21_odom = hm::between(ctx->poses.at(c.key_to), ctx->poses.at(c.key_from));
       switch (cfg.init_method) {
         case LGICP_INIT_ODOMETRY:
-        case LGICP_INIT_FEATURES:  // SAC-IA starts from the odometry guess
+        case LGICP_INIT_FEATURES:  // SAC-IA and TEASER++ start from the odometry guess
+        case LGICP_INIT_TEASERPP:
           guess_from_pose(pp.pose21_odom, true, pp.guess);
           break;
         case LGICP_INIT_ODOM_ROTATION: guess_from_pose(pp.pose21_odom, false, pp.guess); break;

@@ -95,6 +95,9 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
                            CloudFeatures* out);
 int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                      const float guess[16], uint32_t seed, float T_out[16], double* score);
+int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
+                        const float guess[16], float T_out[16], int* used, int* n_matches,
+                        int* n_clique);
 
 inline int fail(lgicp_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];

@@ -276,6 +276,32 @@ int lgicp_sac_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const floa
   return sac_align_device(ctx, fs, ft, guess, 0x5AC1A000u, T_out, fitness_score);
 }
 
+int lgicp_teaser_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const float* src_normals,
+                                   size_t n_src, const float* tgt_xyz, const float* tgt_normals,
+                                   size_t n_tgt, const float guess[16], float T_out[16],
+                                   int32_t* used_teaser, int32_t* n_matches, int32_t* n_clique) {
+  if (!ctx || !guess || !T_out || !used_teaser || !src_xyz || !src_normals || !tgt_xyz ||
+      !tgt_normals)
+    return fail(ctx, LGICP_E_INVALID, "null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  Dev d;
+  float4* d_sx = upload_points(d, src_xyz, n_src, (int)std::max<size_t>(n_src, 1), 1.f);
+  float4* d_sn = upload_points(d, src_normals, n_src, (int)std::max<size_t>(n_src, 1), 0.f);
+  float4* d_tx = upload_points(d, tgt_xyz, n_tgt, (int)std::max<size_t>(n_tgt, 1), 1.f);
+  float4* d_tn = upload_points(d, tgt_normals, n_tgt, (int)std::max<size_t>(n_tgt, 1), 0.f);
+  if (!d_sx || !d_sn || !d_tx || !d_tn) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  CloudFeatures fs, ft;
+  int rc = compute_cloud_features(ctx, d_sx, d_sn, (int)n_src, &fs);
+  if (rc == LGICP_OK) rc = compute_cloud_features(ctx, d_tx, d_tn, (int)n_tgt, &ft);
+  if (rc != LGICP_OK) return rc;
+  int used = 0, nm = 0, nc = 0;
+  rc = teaser_align_device(ctx, fs, ft, guess, T_out, &used, &nm, &nc);
+  *used_teaser = used;
+  if (n_matches) *n_matches = nm;
+  if (n_clique) *n_clique = nc;
+  return rc;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------

@@ -39,6 +39,10 @@ class GpuIcpLoopComputation : public LoopComputation {
                               const pose_graph_msgs::PointCloud& target, float tf_out[16],
                               double& sac_fitness_score);
 
+  // IcpLoopComputation::GetTeaserInitialAlignment (IcpLoopComputation.h:68-70)
+  void GetTeaserInitialAlignment(const pose_graph_msgs::PointCloud& source,
+                                 const pose_graph_msgs::PointCloud& target, float tf_out[16]);
+
   bool CheckReclosingDistance(uint64_t key_from, uint64_t key_to) const;
 
   // seconds; tests replace it (the reference calls ros::Time::now())

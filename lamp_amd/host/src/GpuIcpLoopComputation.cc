@@ -107,18 +107,36 @@ void GpuIcpLoopComputation::KeyedPoseCallback(const pose_graph_msgs::PoseGraph& 
   }
 }
 
+namespace {
+void split(const pose_graph_msgs::PointCloud& c, std::vector<float>& xyz, std::vector<float>& nrm) {
+  xyz.resize(c.size() * 3), nrm.resize(c.size() * 3);
+  for (size_t i = 0; i < c.size(); ++i) {
+    xyz[3 * i] = c[i].x, xyz[3 * i + 1] = c[i].y, xyz[3 * i + 2] = c[i].z;
+    nrm[3 * i] = c[i].normal_x, nrm[3 * i + 1] = c[i].normal_y, nrm[3 * i + 2] = c[i].normal_z;
+  }
+}
+}  // namespace
+
+// IcpLoopComputation::GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081)
+void GpuIcpLoopComputation::GetTeaserInitialAlignment(const pose_graph_msgs::PointCloud& source,
+                                                      const pose_graph_msgs::PointCloud& target,
+                                                      float tf_out[16]) {
+  std::vector<float> sx, sn, tx, tn;
+  split(source, sx, sn);
+  split(target, tx, tn);
+  float T[16];
+  int32_t used = 0;
+  if (lgicp_teaser_initial_alignment(ctx_, sx.data(), sn.data(), source.size(), tx.data(),
+                                     tn.data(), target.size(), tf_out, T, &used, nullptr,
+                                     nullptr) == LGICP_OK)
+    std::memcpy(tf_out, T, sizeof(T));
+}
+
 // IcpLoopComputation::GetSacInitialAlignment (IcpLoopComputation.cc:650-705)
 void GpuIcpLoopComputation::GetSacInitialAlignment(const pose_graph_msgs::PointCloud& source,
                                                    const pose_graph_msgs::PointCloud& target,
                                                    float tf_out[16],
                                                    double& sac_fitness_score) {
-  auto split = [](const pose_graph_msgs::PointCloud& c, std::vector<float>& xyz, std::vector<float>& nrm) {
-    xyz.resize(c.size() * 3), nrm.resize(c.size() * 3);
-    for (size_t i = 0; i < c.size(); ++i) {
-      xyz[3 * i] = c[i].x, xyz[3 * i + 1] = c[i].y, xyz[3 * i + 2] = c[i].z;
-      nrm[3 * i] = c[i].normal_x, nrm[3 * i + 1] = c[i].normal_y, nrm[3 * i + 2] = c[i].normal_z;
-    }
-  };
   std::vector<float> sx, sn, tx, tn;
   split(source, sx, sn);
   split(target, tx, tn);

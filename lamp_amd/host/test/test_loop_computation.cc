@@ -144,6 +144,12 @@ static void OnDevice() {
     CHECK(std::fabs(T_est[3] - 1.f) < 1e-6 && std::fabs(T_est[7] + 0.001f) < 1e-7 && T_est[11] == 0.f);
     CHECK(T_est[0] == 1.f && T_est[5] == 1.f && T_est[10] == 1.f && T_est[1] == 0.f);
     CHECK(fitness_score == 0.0);
+    // the corner has 3 keypoints: 9 descriptor matches are too few for TEASER++, guess kept
+    float T_te[16];
+    for (int i = 0; i < 16; ++i) T_te[i] = (i % 5 == 0) ? 1.f : 0.f;
+    T_te[3] = 0.9f;
+    icp.GetTeaserInitialAlignment(corner, moved, T_te);
+    CHECK(T_te[3] == 0.9f && T_te[0] == 1.f && T_te[7] == 0.f);
     icp.KeyedScanCallback({0, corner});
     icp.KeyedScanCallback({100, moved});
     pose_graph_msgs::PoseGraph kp;

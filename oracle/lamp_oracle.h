@@ -145,6 +145,25 @@ double lo_sac_ia(const float* src_kp, const float* src_feat, int n_src, const fl
                  const float* tgt_feat, int n_tgt, int max_iterations, int k_corr,
                  const float guess[16], uint32_t seed, float T_out[16]);
 
+/* ------------------------------------------------------------------ TEASER++ (parity unpinned) */
+/* GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081) from the keypoints on; see
+ * lo_teaser.c for the restated algorithm.  pairs is [count][2] = (source, target) keypoint ids */
+int lo_teaser_matches(const float* src_feat, int n_src, const float* tgt_feat, int n_tgt, int k,
+                      int32_t* pairs);
+int lo_teaser_clique(const uint8_t* adj, int n, int32_t* clique);
+void lo_teaser_gnc_rotation(const double* src, const double* dst, int n, double noise_bound,
+                            int max_iterations, double gnc_factor, double cost_threshold,
+                            double R[9]);
+double lo_teaser_tls_scalar(const double* X, int n, double range);
+int lo_teaser_solve(const double* src, const double* dst, int n, double noise_bound, double cbar2,
+                    int rotation_max_iterations, double gnc_factor, double cost_threshold,
+                    double R[9], double t[3], int32_t* clique_out, int* n_clique_out);
+double lo_teaser_error_metric(const double* src, const double* dst, int n, const double R[9],
+                              const double t[3], double threshold);
+int lo_teaser_initial_alignment(const float* src_kp, const float* src_feat, int n_src,
+                                const float* tgt_kp, const float* tgt_feat, int n_tgt, float T[16],
+                                int* n_matches_out, int* n_clique_out);
+
 /* ------------------------------------------------------------------ IcpLoopComputation */
 /* IcpLoopComputation.cc:707-768 */
 void lo_icp_cov_point_plane(const float* scan1_xyz, int n1, const float* scan2_normals, int n2,

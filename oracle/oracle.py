@@ -73,6 +73,8 @@ def lib():
         _lib.lo_mat6_det.restype = C.c_double
         _lib.lo_kdtree_build.restype = C.c_void_p
         _lib.lo_sac_ia.restype = C.c_double
+        _lib.lo_teaser_error_metric.restype = C.c_double
+        _lib.lo_teaser_tls_scalar.restype = C.c_double
     return _lib
 
 
@@ -317,6 +319,80 @@ def sac_initial_alignment(src, src_n, tgt, tgt_n, harris_radius=0.1, harris_thre
     ft = fpfh(tgt, tgt_n, tgt[j], features_radius)
     T, fit = sac_ia(src[i], fs, tgt[j], ft, iterations, 5, guess, seed)
     return T, fit, (i, j)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def teaser_matches(src_feat, tgt_feat, k=5):
+    sf, tf = _f32(src_feat), _f32(tgt_feat)
+    pairs = np.empty((len(sf) * k, 2), np.int32)
+    n = lib().lo_teaser_matches(_p(sf, C.c_float), len(sf), _p(tf, C.c_float), len(tf), k,
+                                _p(pairs, C.c_int32))
+    return pairs[:n].copy()
+
+
+def teaser_clique(adj):
+    adj = np.ascontiguousarray(adj, np.uint8)
+    out = np.empty(len(adj), np.int32)
+    m = lib().lo_teaser_clique(_p(adj, C.c_uint8), len(adj), _p(out, C.c_int32))
+    return out[:m].copy()
+
+
+def teaser_gnc_rotation(src, dst, noise_bound=0.5, max_iterations=100, gnc_factor=1.4,
+                        cost_threshold=1e-6):
+    s, d = _f64(src), _f64(dst)
+    R = np.empty(9, np.float64)
+    lib().lo_teaser_gnc_rotation(_p(s, C.c_double), _p(d, C.c_double), len(s),
+                                 C.c_double(noise_bound), max_iterations, C.c_double(gnc_factor),
+                                 C.c_double(cost_threshold), _p(R, C.c_double))
+    return R.reshape(3, 3)
+
+
+def teaser_tls_scalar(x, rng):
+    x = _f64(x)
+    return lib().lo_teaser_tls_scalar(_p(x, C.c_double), len(x), C.c_double(rng))
+
+
+def teaser_solve(src, dst, noise_bound=0.5, cbar2=1.0, max_iterations=100, gnc_factor=1.4,
+                 cost_threshold=1e-6):
+    """RobustRegistrationSolver::solve on matched points [n][3] (double)."""
+    s, d = _f64(src), _f64(dst)
+    R, t = np.empty(9, np.float64), np.empty(3, np.float64)
+    clique = np.empty(max(len(s), 1), np.int32)
+    m = C.c_int()
+    valid = lib().lo_teaser_solve(_p(s, C.c_double), _p(d, C.c_double), len(s),
+                                  C.c_double(noise_bound), C.c_double(cbar2), max_iterations,
+                                  C.c_double(gnc_factor), C.c_double(cost_threshold),
+                                  _p(R, C.c_double), _p(t, C.c_double), _p(clique, C.c_int32),
+                                  C.byref(m))
+    return {"valid": bool(valid), "R": R.reshape(3, 3), "t": t, "clique": clique[:m.value].copy()}
+
+
+def teaser_error_metric(src, dst, R, t, threshold=100.0):
+    s, d, R, t = _f64(src), _f64(dst), _f64(R).reshape(9), _f64(t)
+    return lib().lo_teaser_error_metric(_p(s, C.c_double), _p(d, C.c_double), len(s),
+                                        _p(R, C.c_double), _p(t, C.c_double),
+                                        C.c_double(threshold))
+
+
+def teaser_initial_alignment(src, src_n, tgt, tgt_n, harris_radius=0.1, harris_threshold=5e-9,
+                             features_radius=2.0, guess=None):
+    """GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081).  Returns T, used_teaser,
+    n_matches, n_clique."""
+    src, tgt = _f32(src), _f32(tgt)
+    i, _ = harris_keypoints(src, src_n, harris_radius, harris_threshold)
+    j, _ = harris_keypoints(tgt, tgt_n, harris_radius, harris_threshold)
+    fs = fpfh(src, src_n, src[i], features_radius)
+    ft = fpfh(tgt, tgt_n, tgt[j], features_radius)
+    T = _f32(np.eye(4) if guess is None else guess).reshape(16).copy()
+    sk, tk = _f32(src[i]), _f32(tgt[j])
+    nm, nc = C.c_int(), C.c_int()
+    used = lib().lo_teaser_initial_alignment(_p(sk, C.c_float), _p(fs, C.c_float), len(sk),
+                                             _p(tk, C.c_float), _p(ft, C.c_float), len(tk),
+                                             _p(T, C.c_float), C.byref(nm), C.byref(nc))
+    return T.reshape(4, 4), bool(used), nm.value, nc.value
 
 
 def pose_from_quat(q_wxyz, t):

@@ -433,3 +433,52 @@ def test_submit_features_init_matches_oracle():
         assert r.status == capi.PAIR_INIT_REJECTED and r.iterations == 0
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------ TEASER++ initialisation
+@pytest.mark.parametrize("seed,radius", [(40, 0.3), (43, 0.5)])
+def test_teaser_initial_alignment_matches_oracle(seed, radius):
+    """GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081) against the CPU restatement
+    (parity unpinned against TEASER++ itself, which the reference tree does not hold)."""
+    from lamp_amd import capi
+    c = capi.Context(harris_radius=radius)
+    try:
+        src, sn, tgt, tn, _ = F.make_pair(4000, seed, rot_deg=3.0, trans=0.3)
+        far = np.eye(4, dtype=np.float32); far[:3, 3] = (30, -20, 5)
+        for guess in (None, far):
+            T_ref, used_ref, nm_ref, nc_ref = O.teaser_initial_alignment(
+                src, sn, tgt, tn, harris_radius=radius, guess=guess)
+            T, used, nm, nc = c.teaser_initial_alignment(src, sn, tgt, tn, guess)
+            assert nm == nm_ref and nm > 10
+            assert nc == nc_ref and used == used_ref
+            assert np.allclose(T, T_ref, atol=1e-6)
+        # too few matches: guess returned unchanged
+        corner, cn = F.generate_corner()
+        moved, mn, _ = F.shifted_corner()
+        c2 = capi.Context()
+        T, used, nm, nc = c2.teaser_initial_alignment(corner, cn, moved, mn, far)
+        c2.close()
+        assert nm == 9 and not used and np.array_equal(T, far)
+    finally:
+        c.close()
+
+
+def test_submit_teaser_init_matches_oracle():
+    from lamp_amd import capi
+    radius = 0.3
+    c = capi.Context(init_method=capi.INIT_TEASERPP, harris_radius=radius, transform_thresholding=0)
+    try:
+        src, sn, tgt, tn, T = F.make_pair(4500, 61, rot_deg=2.0, trans=0.2)
+        _register(c, 100, tgt, tn)
+        _register(c, 900, src, sn, t=(0.05, 0.0, 0.0))
+        d = capi.result_to_dict(c.submit([(900, 100)])[0])
+        g = np.eye(4, dtype=np.float32); g[0, 3] = 0.05
+        T0, used, nm, nc = O.teaser_initial_alignment(src, sn, tgt, tn, harris_radius=radius, guess=g)
+        assert np.allclose(d["T_init"], T0, atol=1e-6)
+        assert d["init_fitness"] == (nc if used else 0)
+        ref = O.gicp_align(O.base_gicp_params(solver=O.SOLVER_GN), src, sn, tgt, tn, guess=T0)
+        assert d["converged"] == ref["converged"]
+        ang, te = _rot_err(ref["T"], d["T_icp"])
+        assert ang < 1e-4 and te < 1e-4
+    finally:
+        c.close()

@@ -282,3 +282,68 @@ def test_sac_ia_too_few_keypoints():
     plane, pn = F.generate_plane()
     T, fit, _ = O.sac_initial_alignment(plane, pn, plane, pn, iterations=10)
     assert np.array_equal(T, np.eye(4, dtype=np.float32)) and fit > 1e300
+
+
+# ------------------------------------------------------------------ TEASER++ restatement
+def _teaser_scene(n=200, n_in=60, seed=0, noise=0.05):
+    from scipy.spatial.transform import Rotation as Rsc
+    rng = np.random.default_rng(seed)
+    src = rng.uniform(-10, 10, (n, 3))
+    R = Rsc.from_rotvec([0.5, -0.8, 1.2]).as_matrix()
+    t = np.array([3.0, -2.0, 1.0])
+    dst = src @ R.T + t + rng.normal(0, noise, (n, 3))
+    outl = rng.permutation(n)[: n - n_in]
+    dst[outl] = rng.uniform(-10, 10, (n - n_in, 3))
+    return src, dst, R, t, np.setdiff1d(np.arange(n), outl)
+
+
+def test_teaser_solver_rejects_70_percent_outliers():
+    """Restated TEASER++ (parity unpinned: the library is not in the reference tree and the
+    reference's own test of this path is commented out, test_loop_computation.cc:101-123).
+    Checked through what the algorithm guarantees: the clique holds inliers only, rotation and
+    translation are recovered to the noise level, the truncated error beats the identity's."""
+    src, dst, R, t, inl = _teaser_scene()
+    r = O.teaser_solve(src, dst)
+    assert r["valid"] and set(r["clique"]) <= set(inl) and len(r["clique"]) >= 0.9 * len(inl)
+    assert np.abs(r["R"] - R).max() < 5e-3 and np.abs(r["t"] - t).max() < 0.05
+    assert np.allclose(r["R"] @ r["R"].T, np.eye(3), atol=1e-12) and np.linalg.det(r["R"]) > 0
+    assert O.teaser_error_metric(src, dst, r["R"], r["t"]) < \
+        O.teaser_error_metric(src, dst, np.eye(3), np.zeros(3))
+
+
+def test_teaser_parts():
+    from scipy.spatial.transform import Rotation as Rsc
+    rng = np.random.default_rng(1)
+    R = Rsc.from_rotvec([-1.0, 0.3, 2.0]).as_matrix()
+    x = rng.normal(size=(50, 3))
+    assert np.abs(O.teaser_gnc_rotation(x, x @ R.T) - R).max() < 1e-12
+    # planar and collinear inputs (rank-deficient correlation) still give a proper rotation
+    xp = x.copy(); xp[:, 2] = 0
+    Rp = O.teaser_gnc_rotation(xp, xp @ R.T)
+    assert np.allclose(Rp @ xp.T, R @ xp.T, atol=1e-9) and abs(np.linalg.det(Rp) - 1) < 1e-12
+    # scalar TLS: the consensus of {0.9, 1.0, 1.1} wins over two far outliers
+    assert abs(O.teaser_tls_scalar([1.0, 1.1, 0.9, 5.0, -3.0], 0.5) - 1.0) < 1e-12
+    # clique of a graph made of a 5-clique plus a pendant triangle
+    adj = np.zeros((8, 8), np.uint8)
+    for a in range(5):
+        for b in range(5):
+            adj[a + 2, b + 2] = a != b
+    adj[0, 1] = adj[1, 0] = adj[0, 2] = adj[2, 0] = adj[1, 2] = adj[2, 1] = 1
+    assert list(O.teaser_clique(adj)) == [2, 3, 4, 5, 6]
+    assert len(O.teaser_clique(np.zeros((4, 4), np.uint8))) <= 1
+    # matches: k nearest target descriptors per source descriptor, ascending distance
+    sf = np.zeros((2, 33), np.float32); tf = np.zeros((7, 33), np.float32)
+    tf[:, 0] = [5, 1, 3, 0.5, 9, 2, 4]; sf[1, 0] = 9
+    m = O.teaser_matches(sf, tf, 5)
+    assert m[:5].tolist() == [[0, 3], [0, 1], [0, 5], [0, 2], [0, 6]]
+    assert m[5:].tolist() == [[1, 4], [1, 0], [1, 6], [1, 2], [1, 5]]
+
+
+def test_teaser_initial_alignment_corner():
+    """The reference's (commented-out) corner case has 3 keypoints per cloud: 3 x 3 = 9 matches,
+    not more than 10, so the guess comes back unchanged (IcpLoopComputation.cc:1002,1078)."""
+    corner, cn = F.generate_corner()
+    moved, mn, _ = F.shifted_corner()
+    g = np.eye(4, dtype=np.float32); g[0, 3] = 0.9
+    T, used, n_matches, n_clique = O.teaser_initial_alignment(corner, cn, moved, mn, guess=g)
+    assert n_matches == 9 and not used and np.array_equal(T, g)
