@@ -103,7 +103,10 @@ typedef struct lgicp_config {
   int harris_response;
   /* device-side knobs with no counterpart in the reference */
   size_t workspace_bytes;     /* upper bound for per-batch device scratch (0 = 16 GiB) */
-  int reserved[8];
+  int reserved[8];            /* tuning/diagnostics, 0 = default: [0] queries per lane of the
+                                 exhaustive 1-NN kernel (2, 4, 8); [1] its target splits;
+                                 [2] 1 = use the exhaustive 1-NN kernel instead of the pruned
+                                 one; [3] first-round radius of the pruned search in mm */
 } lgicp_config;
 
 /* pose_graph_msgs/LoopCandidate (pose_graph_msgs/msg/LoopCandidate.msg:1-18) */
@@ -146,6 +149,7 @@ typedef struct lgicp_stats {
   double nn_ms, reduce_ms, solve_ms, cov_ms, post_ms, total_ms; /* hipEvent time, last submit */
   double last_nn_kernel_ms;     /* average duration of one 1-NN launch in the last submit */
   double last_nn_evals_per_launch;
+  double nn_executed_evals;     /* distances the pruned 1-NN kernel actually evaluated, last submit */
 } lgicp_stats;
 
 typedef struct lgicp_ctx lgicp_ctx;

@@ -62,7 +62,7 @@ class Stats(C.Structure):
                 ("nn_distance_evals", C.c_double), ("nn_ms", C.c_double), ("reduce_ms", C.c_double),
                 ("solve_ms", C.c_double), ("cov_ms", C.c_double), ("post_ms", C.c_double),
                 ("total_ms", C.c_double), ("last_nn_kernel_ms", C.c_double),
-                ("last_nn_evals_per_launch", C.c_double)]
+                ("last_nn_evals_per_launch", C.c_double), ("nn_executed_evals", C.c_double)]
 
 
 class LgicpError(RuntimeError):

@@ -1,0 +1,244 @@
+// knn_pruned.hip — exact 1-NN correspondence search that skips provably irrelevant targets.
+//
+// Same contract as the exhaustive kernel in knn.hip (reference: the kd-tree lookups of
+// lamp_utils/include/lamp_utils/gicp.hpp:463-498 and the two lookup passes at
+// loop_closure/src/IcpLoopComputation.cc:553-566,586): FLANN L2_Simple<float> arithmetic
+// d = (dx*dx + dy*dy) + dz*dz with every operation rounded separately, lowest target index
+// among exactly equidistant targets.  What changes is how much of the target is looked at.
+//
+// Layout.  Every cloud carries a spatial index built once (spatial_index.hip): its points in
+// Morton order cut into tiles of SI_TILE points, each point stored with its original index,
+// plus the axis-aligned box of every tile and the Morton visiting order of the cloud's own
+// points.  One wave owns 64 Morton-consecutive queries — a compact patch of surface — and keeps
+// the patch's box.  The float box-to-box gap, squared and summed in the same operation order as
+// a point distance, never exceeds the computed distance of any query/target pair drawn from
+// the two boxes (rounding is monotonic), so a tile whose gap exceeds every lane's current best
+// cannot improve or tie any lane and is skipped without touching its points.
+//
+// Sweep.  Tiles are visited in rounds of doubling radius: round k looks at tiles whose gap to
+// the patch lies in (r_{k-1}^2, r_k^2]; the sweep ends when every lane's best is <= r_k^2
+// (nothing further out can matter) or, for the bounded search of the GICP loop, when r_k^2
+// reaches the correspondence threshold (the loop ignores matches at or beyond it,
+// gicp.hpp:476).  Inside a round the 64 lanes test 64 tile boxes at once; for each survivor the
+// box is broadcast and every lane tests its own query against it, and the tile is walked only
+// if some lane can still improve or tie.  Tile coordinates arrive through scalar loads, two
+// targets per packed instruction.  As in the exhaustive kernel a lane tracks only the minimum of each group
+// of 8 targets and the first group that lowered it; the index is recovered afterwards, and the
+// rare exact tie between groups is resolved by a second walk.
+#include "lgicp_device.h"
+
+namespace lgicp {
+
+namespace {
+
+// max over the wave of a non-negative float (bit patterns order like the values)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  unsigned u = __float_as_uint(v);
+  // row_shr 1,2,4,8 within rows of 16, then row_bcast 15 and 31 across rows
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x111, 0xf, 0xf, false));
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x112, 0xf, 0xf, false));
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x114, 0xf, 0xf, false));
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x118, 0xf, 0xf, false));
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x142, 0xa, 0xf, false));
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x143, 0xc, 0xf, false));
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u, 63));
+}
+
+__device__ __forceinline__ float wave_min_f(float v) {  // NaN lanes are ignored by fminf
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fminf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int GROUP = 8;  // targets whose minimum is tracked together
+
+// tile coordinates are read through the constant address space: with wave-uniform addresses
+// the compiler fetches them with scalar loads and feeds them to the vector ALU as scalar
+// operands, so a target costs no vector register, LDS bandwidth or vector-memory instruction
+typedef const __attribute__((address_space(4))) float cfloat;
+
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
+    const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
+    const PairState* __restrict__ st, const int4* __restrict__ bmap, int final_pass, float cap,
+    float r0sq, unsigned long long* __restrict__ counters) {
+  const int4 bm = bmap[blockIdx.x];
+  const int pair = bm.x;
+  const PairState& S = st[pair];
+  if (!final_pass && !S.active) return;  // block-uniform
+  const PairDev& P = pairs[pair];
+  const CloudDev& TG = clouds[P.tgt_cloud];
+  const CloudDev& SC = clouds[P.src_cloud];
+  const int lane = threadIdx.x & 63;
+  const int slot = (bm.y * (NNP_THREADS / 64) + (threadIdx.x >> 6)) * 64 + lane;
+  if (slot - lane >= SC.n_q) return;  // wave-uniform: this wave has no queries
+  const float4* __restrict__ qsrc = final_pass ? SC.xyz : P.out;
+  const float* Tm = final_pass ? S.Tfinal : S.T;
+
+  const int qi = slot < SC.n_q ? SC.qorder[slot] : -1;
+  float x = __builtin_nanf(""), y = x, z = x;
+  if (qi >= 0) {
+    const float4 p = qsrc[qi];
+    x = ((Tm[0] * p.x + Tm[1] * p.y) + Tm[2] * p.z) + Tm[3];
+    y = ((Tm[4] * p.x + Tm[5] * p.y) + Tm[6] * p.z) + Tm[7];
+    z = ((Tm[8] * p.x + Tm[9] * p.y) + Tm[10] * p.z) + Tm[11];
+  }
+  const bool finite = __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+  if (__ballot(finite) == 0) {  // nothing to look up
+    if (qi >= 0) P.keys[qi] = NNKEY_NONE;
+    return;
+  }
+  // the patch's box over its finite queries
+  const float nanv = __builtin_nanf("");
+  const float fx = finite ? x : nanv, fy = finite ? y : nanv, fz = finite ? z : nanv;
+  const float qx0 = wave_min_f(fx), qy0 = wave_min_f(fy), qz0 = wave_min_f(fz);
+  const float qx1 = wave_max_f(fx), qy1 = wave_max_f(fy), qz1 = wave_max_f(fz);
+  const v2f x2 = {x, x}, y2 = {y, y}, z2 = {z, z};
+
+  const float4* __restrict__ tmin = TG.tmin;
+  const float4* __restrict__ tmax = TG.tmax;
+  const int n_tiles = TG.n_tiles;
+  cfloat* const tiles = (cfloat*)(uintptr_t)TG.sxyz;
+
+  float bestd = __builtin_inff();  // smallest finite distance so far
+  int bgrp = -1;                   // first group (tile * 4 + k) that reached it
+  bool tie = false;                // another group reached exactly the same distance
+  unsigned visited = 0;
+  float lo = -1.0f, hi = __builtin_fminf(r0sq, cap);
+  float worst = __builtin_inff();  // wave-uniform: max over finite lanes of bestd, per round
+  const int n_steps = (n_tiles + 63) / 64;
+
+  for (;;) {
+    // boxes of the next 64 tiles are fetched while the current 64 are being worked on
+    float4 nb0 = make_float4(0.f, 0.f, 0.f, 0.f), nb1 = nb0;
+    if (lane < n_tiles) nb0 = tmin[lane], nb1 = tmax[lane];
+    for (int step = 0; step < n_steps; ++step) {
+      const float4 b0 = nb0, b1 = nb1;
+      const int t = step * 64 + lane;
+      if (t + 64 < n_tiles) nb0 = tmin[t + 64], nb1 = tmax[t + 64];
+      // patch-to-tile gap: which of these 64 tiles belong to this round at all
+      const float gx = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.x - qx1, qx0 - b1.x));
+      const float gy = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.y - qy1, qy0 - b1.y));
+      const float gz = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.z - qz1, qz0 - b1.z));
+      const float lb = (gx * gx + gy * gy) + gz * gz;
+      unsigned long long mask = __ballot(t < n_tiles && lb > lo && lb <= hi && lb <= worst);
+      while (mask) {
+        const int b = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        // query-to-tile gap per lane: the tile is skipped unless it can improve or tie some
+        // lane's current best (and, in the bounded search, lies inside the cap for it)
+        const float x0 = rdlane(b0.x, b), y0 = rdlane(b0.y, b), z0 = rdlane(b0.z, b);
+        const float x1 = rdlane(b1.x, b), y1 = rdlane(b1.y, b), z1 = rdlane(b1.z, b);
+        const float hx = __builtin_fmaxf(0.f, __builtin_fmaxf(x0 - x, x - x1));
+        const float hy = __builtin_fmaxf(0.f, __builtin_fmaxf(y0 - y, y - y1));
+        const float hz = __builtin_fmaxf(0.f, __builtin_fmaxf(z0 - z, z - z1));
+        const float gl = (hx * hx + hy * hy) + hz * hz;
+        if (__ballot(finite && gl <= bestd && gl <= cap) == 0) continue;
+        const int tile = step * 64 + b;
+        cfloat* const tx = tiles + (size_t)tile * (4 * SI_TILE);
+        cfloat* const ty = tx + SI_TILE;
+        cfloat* const tz = tx + 2 * SI_TILE;
+#pragma unroll
+        for (int g = 0; g < SI_TILE / GROUP; ++g) {
+          float m = __builtin_inff();
+#pragma unroll
+          for (int j = 0; j < GROUP; j += 2) {
+            const int kk = g * GROUP + j;
+            const v2f px = {tx[kk], tx[kk + 1]}, py = {ty[kk], ty[kk + 1]}, pz = {tz[kk], tz[kk + 1]};
+            const v2f dx = x2 - px, dy = y2 - py, dz = z2 - pz;
+            const v2f d = (dx * dx + dy * dy) + dz * dz;
+            m = __builtin_fminf(__builtin_fminf(m, d.x), d.y);
+          }
+          // +inf and NaN distances (padding, overflow) never count
+          const bool lower = m < bestd;
+          tie = lower ? false : (tie || m == bestd);
+          bestd = lower ? m : bestd;
+          bgrp = lower ? tile * (SI_TILE / GROUP) + g : bgrp;
+        }
+        ++visited;
+      }
+    }
+    worst = wave_max_nonneg(finite ? bestd : 0.f);
+    if (hi >= cap || worst <= hi) break;
+    lo = hi;
+    hi = __builtin_fminf(hi * 4.0f, cap);
+    if (!(hi < 1.0e30f)) hi = cap;
+  }
+
+  // lowest original index inside the winning group
+  const int* __restrict__ tidx = reinterpret_cast<const int*>(TG.sxyz);
+  const float* __restrict__ tf = reinterpret_cast<const float*>(TG.sxyz);
+  int idx = 0x7FFFFFFF;
+  if (finite && bgrp >= 0) {
+    const size_t o = (size_t)(bgrp / (SI_TILE / GROUP)) * (4 * SI_TILE) + (bgrp % (SI_TILE / GROUP)) * GROUP;
+#pragma unroll
+    for (int j = 0; j < GROUP; ++j) {
+      const float dx = x - tf[o + j], dy = y - tf[o + SI_TILE + j], dz = z - tf[o + 2 * SI_TILE + j];
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      const int id = tidx[o + 3 * SI_TILE + j];
+      idx = (d == bestd && id < idx) ? id : idx;
+    }
+  }
+  // Rare: another group holds a target at exactly the same distance.  Re-walk every tile that
+  // can contain one and take the lowest index among the exact matches.
+  tie = tie && finite && bgrp >= 0;
+  if (__ballot(tie)) {
+    const float tworst = wave_max_nonneg(tie ? bestd : 0.f);
+    for (int base = 0; base < n_tiles; base += 64) {
+      const int t = base + lane;
+      float lb = __builtin_inff();
+      if (t < n_tiles) {
+        const float4 b0 = tmin[t], b1 = tmax[t];
+        const float gx = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.x - qx1, qx0 - b1.x));
+        const float gy = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.y - qy1, qy0 - b1.y));
+        const float gz = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.z - qz1, qz0 - b1.z));
+        lb = (gx * gx + gy * gy) + gz * gz;
+      }
+      unsigned long long mask = __ballot(t < n_tiles && lb <= tworst);
+      while (mask) {
+        const int b = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const size_t o = (size_t)(base + b) * (4 * SI_TILE);
+        for (int j = 0; j < SI_TILE; ++j) {
+          const float dx = x - tf[o + j], dy = y - tf[o + SI_TILE + j], dz = z - tf[o + 2 * SI_TILE + j];
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          const int id = tidx[o + 3 * SI_TILE + j];
+          idx = (tie && d == bestd && id >= 0 && id < idx) ? id : idx;
+        }
+      }
+    }
+  }
+
+  if (qi >= 0)
+    P.keys[qi] = (finite && bgrp >= 0 && idx != 0x7FFFFFFF)
+                     ? (((nnkey_t)__float_as_uint(bestd) << 32) | (unsigned)idx)
+                     : NNKEY_NONE;
+  // spread over NN_COUNTER_SLOTS addresses: one hot address would serialise every wave of the
+  // launch in a single L2 channel
+  if (counters && lane == 0)
+    atomicAdd(&counters[(blockIdx.x * (NNP_THREADS / 64) + (threadIdx.x >> 6)) & (NN_COUNTER_SLOTS - 1)],
+              (unsigned long long)visited * SI_TILE * 64ull);
+}
+
+hipError_t launch_nn_pruned(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
+                            const int4* bmap, int n_blocks, bool final_pass, float cap, float r0sq,
+                            unsigned long long* counters, hipStream_t stream) {
+  if (n_blocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(nn_pruned_kernel, dim3(n_blocks), dim3(NNP_THREADS), 0, stream, clouds, pairs,
+                     st, bmap, (int)final_pass, cap, r0sq, counters);
+  return hipGetLastError();
+}
+
+}  // namespace lgicp

@@ -22,7 +22,10 @@
 #include "host_math.h"
 #include "lgicp_device.h"
 
+#include <limits>
+
 #include "lgicp_internal.h"
+#include "spatial_index.h"
 
 namespace {
 
@@ -66,6 +69,35 @@ void xcd_permute(std::vector<T>& v) {
 }
 
 }  // namespace
+
+namespace lgicp_detail {
+
+// Morton order on the host, tiles and boxes on the device; the cloud is one segment.
+int build_keyframe_index(lgicp_ctx* ctx, Keyframe* kf, const float* xyz, size_t stride_floats) {
+  const int n = kf->n;
+  kf->n_tiles = (n + SI_TILE - 1) / SI_TILE;
+  kf->n_q = round_up(n, 64);
+  if (n == 0) return LGICP_OK;
+  const std::vector<int> order = si::morton_order(xyz, (size_t)n, stride_floats);
+  HIP_TRY(ctx, hipMalloc((void**)&kf->d_order, sizeof(int) * (size_t)n));
+  HIP_TRY(ctx, hipMalloc((void**)&kf->d_sxyz, sizeof(float4) * (size_t)kf->n_tiles * SI_TILE));
+  HIP_TRY(ctx, hipMalloc((void**)&kf->d_tmin, sizeof(float4) * (size_t)kf->n_tiles));
+  HIP_TRY(ctx, hipMalloc((void**)&kf->d_tmax, sizeof(float4) * (size_t)kf->n_tiles));
+  HIP_TRY(ctx, hipMalloc((void**)&kf->d_qorder, sizeof(int) * (size_t)kf->n_q));
+  HIP_TRY(ctx, hipMemcpy(kf->d_order, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  IndexSegDev g;
+  std::memset(&g, 0, sizeof(g));
+  g.xyz = kf->d_xyz, g.order = kf->d_order, g.sxyz = kf->d_sxyz, g.tmin = kf->d_tmin;
+  g.tmax = kf->d_tmax, g.qorder = kf->d_qorder;
+  g.point_off = 0, g.tile_off = 0, g.n = n, g.last = 1, g.n_q = kf->n_q;
+  HIP_TRY(ctx, ctx->d_isegs.reserve(1));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_isegs.p, &g, sizeof(g), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, launch_index_fill(ctx->d_isegs.p, 1, n, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LGICP_OK;
+}
+
+}  // namespace lgicp_detail
 
 extern "C" {
 
@@ -130,6 +162,11 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
   if (ctx->cfg.workspace_bytes == 0) ctx->cfg.workspace_bytes = (size_t)16 << 30;
   if (cfg->reserved[0] == 2 || cfg->reserved[0] == 4 || cfg->reserved[0] == 8)
     ctx->nn_variant = cfg->reserved[0];
+  ctx->nn_exhaustive = cfg->reserved[2] == 1;
+  if (cfg->reserved[3] > 0) {
+    const float r0 = 1e-3f * (float)cfg->reserved[3];
+    ctx->nn_r0sq = r0 * r0;
+  }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_done, sizeof(int) * 65536, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
@@ -143,10 +180,9 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->cfg.device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (auto& kv : ctx->scans) {
-    if (kv.second.d_xyz) (void)hipFree(kv.second.d_xyz);
-    if (kv.second.d_nrm) (void)hipFree(kv.second.d_nrm);
-  }
+  for (auto& kv : ctx->scans) kv.second.free_device();
+  ctx->d_isegs.release();
+  ctx->d_counters.release();
   ctx->arena.release();
   ctx->d_clouds.release();
   ctx->d_pairs.release();
@@ -192,6 +228,11 @@ int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const flo
                          hipMemcpyHostToDevice));
   if (n)
     HIP_TRY(ctx, hipMemcpy(kf.d_nrm, hn.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+  const int rc = build_keyframe_index(ctx, &kf, xyz, sf);
+  if (rc != LGICP_OK) {
+    kf.free_device();
+    return rc;
+  }
   ctx->scans.emplace(key, kf);
   return 1;
 }
@@ -264,7 +305,11 @@ int plan_cloud(lgicp_ctx* ctx, BatchPlan& bp, uint64_t key, bool accumulate) {
   for (auto& s : cp.segs) cp.n += ctx->scans.at(s.first).n;
   cp.n_pad = std::max(NN_TILE, round_up(cp.n, NN_TILE));
   bp.bytes += (size_t)cp.n * 48 + 256;                              // covariances
-  if (acc) bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 16 + 512;  // xyz + normals
+  if (acc) {
+    bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 16 + 512;  // xyz + normals
+    // spatial index: tile-ordered points, boxes, visiting order
+    bp.bytes += (size_t)cp.n * 22 + (cp.segs.size() + 1) * (SI_TILE * 16 + 64) + 2048;
+  }
   const int idx = (int)bp.clouds.size();
   bp.clouds.push_back(std::move(cp));
   bp.cloud_index[id] = idx;
@@ -295,7 +340,8 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
 
   std::vector<CloudDev> h_clouds((size_t)n_clouds);
   std::vector<SegmentDev> h_segs;
-  int max_seg_n = 0, max_cloud_n = 0;
+  std::vector<IndexSegDev> h_isegs;
+  int max_seg_n = 0, max_cloud_n = 0, max_iseg_n = 0;
   for (int c = 0; c < n_clouds; ++c) {
     CloudPlan& cp = bp.clouds[c];
     const Keyframe& kf = ctx->scans.at(cp.key);
@@ -308,11 +354,38 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
     if (!cp.accumulated) {
       cd.xyz = kf.d_xyz;
       cd.nrm = kf.d_nrm;
+      cd.sxyz = kf.d_sxyz, cd.tmin = kf.d_tmin, cd.tmax = kf.d_tmax, cd.qorder = kf.d_qorder;
+      cd.n_tiles = kf.n_tiles, cd.n_q = kf.n_q;
     } else {
       float4* xyz = ar.take<float4>((size_t)cp.n_pad);
       float4* nrm = ar.take<float4>((size_t)cp.n);
       cd.xyz = xyz;
       cd.nrm = nrm;
+      {  // index = concatenation of the member keyframes' segments
+        int tiles = (kf.n + SI_TILE - 1) / SI_TILE;
+        for (auto& sg : cp.segs) tiles += (ctx->scans.at(sg.first).n + SI_TILE - 1) / SI_TILE;
+        cd.n_tiles = tiles;
+        cd.n_q = round_up(cp.n, 64);
+        float4* sx = ar.take<float4>((size_t)tiles * SI_TILE);
+        float4* t0 = ar.take<float4>((size_t)tiles);
+        float4* t1 = ar.take<float4>((size_t)tiles);
+        int* qo = ar.take<int>((size_t)cd.n_q);
+        cd.sxyz = sx, cd.tmin = t0, cd.tmax = t1, cd.qorder = qo;
+        IndexSegDev g;
+        std::memset(&g, 0, sizeof(g));
+        g.xyz = xyz, g.sxyz = sx, g.tmin = t0, g.tmax = t1, g.qorder = qo, g.n_q = cd.n_q;
+        int poff = 0, toff = 0;
+        auto add = [&](const Keyframe& k, bool last) {
+          g.order = k.d_order, g.point_off = poff, g.tile_off = toff, g.n = k.n, g.last = last;
+          if (k.n > 0 || last) h_isegs.push_back(g);
+          max_iseg_n = std::max(max_iseg_n, k.n);
+          poff += k.n;
+          toff += (k.n + SI_TILE - 1) / SI_TILE;
+        };
+        add(kf, cp.segs.empty());
+        for (size_t si = 0; si < cp.segs.size(); ++si)
+          add(ctx->scans.at(cp.segs[si].first), si + 1 == cp.segs.size());
+      }
       int off = 0;
       SegmentDev s;
       std::memset(&s, 0, sizeof(s));
@@ -382,7 +455,7 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   // Rebuilt whenever pairs drop out of the outer loop: the 1-NN grid covers the active pairs
   // only, and when few are left their targets are split over several workgroups so that the
   // launch still offers >= ~4 workgroups per CU.
-  const int QB = nn_queries_per_block(ctx->nn_variant);
+  const int QB = ctx->nn_exhaustive ? nn_queries_per_block(ctx->nn_variant) : NNP_THREADS;
   std::vector<int4> h_bmap_nn, h_bmap_red;
   std::vector<int> h_ints((size_t)2 * n_pairs + 4, 0);
   bool any_split = false;
@@ -390,7 +463,9 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
     long long base_blocks = 0;
     for (int p : act) base_blocks += (h_pairs[p].n_src + QB - 1) / QB;
     int splits = 1;
-    if (cfg.reserved[1] > 0)
+    if (!ctx->nn_exhaustive)
+      splits = 1;  // a wave of the pruned kernel sweeps the whole target index
+    else if (cfg.reserved[1] > 0)
       splits = cfg.reserved[1];
     else
       while (base_blocks * splits < 1024 && splits < 64) splits *= 2;
@@ -436,6 +511,12 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   HIP_TRY(ctx, ctx->d_bmap_red.reserve(h_bmap_red.size()));
   HIP_TRY(ctx, ctx->d_ints.reserve(h_ints.size()));
   HIP_TRY(ctx, ctx->d_partials.reserve((size_t)n_pairs * RED_MAX_CHUNKS * NSTAT));
+  HIP_TRY(ctx, ctx->d_isegs.reserve(std::max<size_t>(h_isegs.size(), 1)));
+  HIP_TRY(ctx, ctx->d_counters.reserve(NN_COUNTER_SLOTS));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(unsigned long long) * NN_COUNTER_SLOTS, st));
+  if (!h_isegs.empty())
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_isegs.p, h_isegs.data(), sizeof(IndexSegDev) * h_isegs.size(),
+                                hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_clouds.p, h_clouds.data(), sizeof(CloudDev) * n_clouds,
                               hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
@@ -464,6 +545,7 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
     if (bp.clouds[c].accumulated)
       HIP_TRY(ctx, launch_pad_fill(const_cast<float4*>(h_clouds[c].xyz), h_clouds[c].n,
                                    h_clouds[c].n_pad, st));
+  HIP_TRY(ctx, launch_index_fill(ctx->d_isegs.p, (int)h_isegs.size(), max_iseg_n, st));
   if (cfg.covariance_from_knn) {
     for (int c = 0; c < n_clouds; ++c)
       HIP_TRY(ctx, launch_cov_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
@@ -539,6 +621,25 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   sp.max_iterations = cfg.iterations;
   sp.max_inner_iterations = cfg.optimizer_iterations;
   int* d_done = ctx->d_ints.p + off_done;
+  // One 1-NN pass over the pairs of the current block map.  Inside the GICP loop only matches
+  // closer than the correspondence threshold are used (gicp.hpp:476), so the pruned search is
+  // capped just above it; the pass after the loop is exact for every point.
+  float nn_cap = std::nextafter((float)sp.corr_dist2, std::numeric_limits<float>::infinity());
+  if (cfg.reserved[4] > 0)  // diagnostics only: a smaller cap drops correspondences
+    nn_cap = 1e-6f * (float)cfg.reserved[4] * (float)cfg.reserved[4];
+  auto nn_pass = [&](bool final_pass) -> hipError_t {
+    if (!ctx->nn_exhaustive)
+      return launch_nn_pruned(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, ctx->d_bmap_nn.p,
+                              (int)h_bmap_nn.size(), final_pass,
+                              final_pass ? std::numeric_limits<float>::infinity() : nn_cap,
+                              ctx->nn_r0sq, ctx->d_counters.p, st);
+    if (any_split) {
+      hipError_t e = launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, final_pass, st);
+      if (e != hipSuccess) return e;
+    }
+    return launch_nn_search(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, ctx->d_bmap_nn.p,
+                            (int)h_bmap_nn.size(), final_pass, any_split, ctx->nn_variant, st);
+  };
   std::vector<int> active;
   for (int p = 0; p < n_pairs; ++p)
     if (h_state[p].active) active.push_back(p);
@@ -557,11 +658,7 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   while (!active.empty() && outer < cfg.iterations + 1) {
     hipEvent_t a = ctx->event(), b = ctx->event(), c = ctx->event(), d = ctx->event();
     HIP_TRY(ctx, hipEventRecord(a, st));
-    if (any_split)
-      HIP_TRY(ctx, launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, false, st));
-    HIP_TRY(ctx, launch_nn_search(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
-                                  ctx->d_bmap_nn.p, (int)h_bmap_nn.size(), false, any_split,
-                                  ctx->nn_variant, st));
+    HIP_TRY(ctx, nn_pass(false));
     HIP_TRY(ctx, hipEventRecord(b, st));
     HIP_TRY(ctx, launch_gicp_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
                                     ctx->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
@@ -602,10 +699,7 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   HIP_TRY(ctx, hipStreamSynchronize(st));
   hipEvent_t ev_post0 = ctx->event(), ev_post1 = ctx->event(), ev_post2 = ctx->event();
   HIP_TRY(ctx, hipEventRecord(ev_post0, st));
-  if (any_split)
-    HIP_TRY(ctx, launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, true, st));
-  HIP_TRY(ctx, launch_nn_search(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, ctx->d_bmap_nn.p,
-                                (int)h_bmap_nn.size(), true, any_split, ctx->nn_variant, st));
+  HIP_TRY(ctx, nn_pass(true));
   HIP_TRY(ctx, hipEventRecord(ev_post1, st));
   HIP_TRY(ctx, launch_post_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
                                   ctx->d_bmap_red.p, (int)h_bmap_red.size(), ctx->d_partials.p,
@@ -618,7 +712,11 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
                               hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(h_state.data(), ctx->d_state.p, sizeof(PairState) * n_pairs,
                               hipMemcpyDeviceToHost, st));
+  std::vector<unsigned long long> h_counters(NN_COUNTER_SLOTS, 0);
+  HIP_TRY(ctx, hipMemcpyAsync(h_counters.data(), ctx->d_counters.p,
+                              sizeof(unsigned long long) * NN_COUNTER_SLOTS, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  for (unsigned long long v : h_counters) ctx->stats.nn_executed_evals += (double)v;
 
   // ---- timing ------------------------------------------------------------------------------
   auto sum_ms = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
@@ -737,6 +835,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   HIP_TRY(ctx, hipSetDevice(cfg.device));
   ctx->stats.nn_ms = ctx->stats.reduce_ms = ctx->stats.solve_ms = ctx->stats.cov_ms =
       ctx->stats.post_ms = ctx->stats.total_ms = 0;
+  ctx->stats.nn_executed_evals = 0;
 
   size_t i = 0;
   while (i < n) {
@@ -845,8 +944,7 @@ extern "C" int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* sr
   for (uint64_t k : {ks, kt}) {
     auto it = ctx->scans.find(k);
     if (it != ctx->scans.end()) {
-      if (it->second.d_xyz) (void)hipFree(it->second.d_xyz);
-      if (it->second.d_nrm) (void)hipFree(it->second.d_nrm);
+      it->second.free_device();
       ctx->scans.erase(it);
     }
     ctx->poses.erase(k);

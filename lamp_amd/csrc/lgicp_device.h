@@ -20,6 +20,11 @@ static constexpr int NN_THREADS = 256;
 static constexpr int NN_TILE = 1024;  // target points per LDS tile (12 KiB as SoA floats)
 static constexpr int NN_GROUP = 8;    // targets whose minimum is tracked together
 
+// spatial index of a cloud: Morton-ordered points in tiles of SI_TILE with one box per tile
+static constexpr int SI_TILE = 32;
+static constexpr int NNP_THREADS = 64;   // one wave of 64 queries per workgroup: waves finish independently
+static constexpr int NN_COUNTER_SLOTS = 4096;  // the evaluated-distance counter is spread over these
+
 // number of f64 statistics per pair and outer iteration: 10 x 6 second moments
 // sum(u_k u_l M), 4 x 3 first moments sum(u_k M r0), sum(r0^T M r0), correspondence count
 static constexpr int NSTAT = 74;
@@ -35,6 +40,15 @@ struct CloudDev {
   const double* cov;  // n x 6: c00 c01 c02 c11 c12 c22
   int n;
   int n_pad;
+  // spatial index (spatial_index.hip)
+  const float4* sxyz;  // n_tiles tiles of SI_TILE points in Morton order, each tile stored as
+                       // x[SI_TILE] y[SI_TILE] z[SI_TILE] original-index[SI_TILE]; unused
+                       // slots hold +inf coordinates and index -1
+  const float4* tmin;  // n_tiles box corners
+  const float4* tmax;
+  const int* qorder;   // n_q original indices in Morton order, -1 in the padding
+  int n_tiles;
+  int n_q;             // n rounded up to a multiple of 64
   // NormalizePCloud constants (used only for the un-accumulated source keyframe)
   float centroid[3];
   float factor;
@@ -100,6 +114,31 @@ hipError_t launch_nn_search(const CloudDev* clouds, const PairDev* pairs, const 
                             const int4* bmap, int n_blocks, bool final_pass, bool any_split,
                             int variant, hipStream_t stream);
 int nn_queries_per_block(int variant);
+
+// pruned exact 1-NN (knn_pruned.hip).  bmap entry: x = pair, y = group of NNP_THREADS queries.
+// cap = squared radius beyond which matches are not needed (+inf: exact for every query),
+// r0sq = squared radius of the first round; distances evaluated are added into
+// counters[0 .. NN_COUNTER_SLOTS) (sum them)
+hipError_t launch_nn_pruned(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
+                            const int4* bmap, int n_blocks, bool final_pass, float cap, float r0sq,
+                            unsigned long long* counters, hipStream_t stream);
+
+// One segment of a cloud's spatial index: n points of `xyz + point_off` visited in `order`
+// (a permutation of 0..n-1) fill tiles tile_off.. of the cloud's index arrays.
+struct IndexSegDev {
+  const float4* xyz;   // the cloud's points in original order
+  const int* order;    // Morton order of this segment's own points
+  float4* sxyz;
+  float4* tmin;
+  float4* tmax;
+  int* qorder;
+  int point_off;       // first original index of the segment inside the cloud
+  int tile_off;
+  int n;
+  int last;            // 1: also pad qorder up to n_q after this segment
+  int n_q;
+};
+hipError_t launch_index_fill(const IndexSegDev* segs, int n_segs, int max_n, hipStream_t stream);
 hipError_t launch_keys_fill(const PairDev* pairs, const PairState* st, int n_pairs, int max_n,
                             bool final_pass, hipStream_t stream);
 hipError_t launch_keys_unpack(const nnkey_t* keys, int n, int32_t* idx, float* d2,

@@ -24,6 +24,21 @@ struct Keyframe {
   int n_pad = 0;
   float4* d_xyz = nullptr;  // n_pad
   float4* d_nrm = nullptr;  // n
+  // spatial index of the keyframe on its own (see CloudDev)
+  int n_tiles = 0;
+  int n_q = 0;
+  int* d_order = nullptr;   // n: Morton visiting order
+  float4* d_sxyz = nullptr;
+  float4* d_tmin = nullptr;
+  float4* d_tmax = nullptr;
+  int* d_qorder = nullptr;
+  void free_device() {
+    for (void* p : {(void*)d_xyz, (void*)d_nrm, (void*)d_order, (void*)d_sxyz, (void*)d_tmin,
+                    (void*)d_tmax, (void*)d_qorder})
+      if (p) (void)hipFree(p);
+    d_xyz = d_nrm = d_sxyz = d_tmin = d_tmax = nullptr;
+    d_order = d_qorder = nullptr;
+  }
 };
 
 template <typename T>
@@ -68,6 +83,10 @@ struct lgicp_ctx {
   DevBuf<int4> d_bmap_nn, d_bmap_red;
   DevBuf<int> d_ints;  // n_chunks[n_pairs] | scan1 ids | n_done
   DevBuf<double> d_partials;
+  DevBuf<IndexSegDev> d_isegs;
+  DevBuf<unsigned long long> d_counters;
+  bool nn_exhaustive = false;  // reserved[2] = 1: the dense 1-NN kernel instead of the pruned one
+  float nn_r0sq = 1.0f / 64.0f;  // squared radius of the pruned search's first round
   int* h_done = nullptr;  // pinned
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -91,6 +110,8 @@ struct CloudFeatures {
   std::vector<float> xyz;     // [k][3]
   std::vector<float> feat;    // [k][33]
 };
+// builds the spatial index of a device-resident cloud treated as one segment
+int build_keyframe_index(lgicp_ctx* ctx, Keyframe* kf, const float* xyz, size_t stride_floats);
 int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
                            CloudFeatures* out);
 int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,

@@ -76,6 +76,25 @@ int lgicp_nn_search(lgicp_ctx* ctx, const float T[16], const float* src_xyz, siz
   std::memset(hc, 0, sizeof(hc));
   hc[0].xyz = d_src, hc[0].n = (int)n_src, hc[0].n_pad = n_pad_s;
   hc[1].xyz = d_tgt, hc[1].n = (int)n_tgt, hc[1].n_pad = n_pad_t;
+  struct IndexOwner {  // the index arrays of a cloud whose points belong to someone else
+    Keyframe kf;
+    ~IndexOwner() {
+      kf.d_xyz = kf.d_nrm = nullptr;
+      kf.free_device();
+    }
+  } is, it;
+  if (!ctx->nn_exhaustive) {
+    is.kf.n = (int)n_src, is.kf.d_xyz = d_src;
+    it.kf.n = (int)n_tgt, it.kf.d_xyz = d_tgt;
+    int rc = build_keyframe_index(ctx, &is.kf, src_xyz, 3);
+    if (rc == LGICP_OK) rc = build_keyframe_index(ctx, &it.kf, tgt_xyz, 3);
+    if (rc != LGICP_OK) return rc;
+    const Keyframe* k2[2] = {&is.kf, &it.kf};
+    for (int c = 0; c < 2; ++c) {
+      hc[c].sxyz = k2[c]->d_sxyz, hc[c].tmin = k2[c]->d_tmin, hc[c].tmax = k2[c]->d_tmax;
+      hc[c].qorder = k2[c]->d_qorder, hc[c].n_tiles = k2[c]->n_tiles, hc[c].n_q = k2[c]->n_q;
+    }
+  }
   PairDev hp;
   std::memset(&hp, 0, sizeof(hp));
   hp.src_cloud = 0, hp.tgt_cloud = 1, hp.scan1_cloud = 0, hp.scan2_cloud = 1;
@@ -84,10 +103,12 @@ int lgicp_nn_search(lgicp_ctx* ctx, const float T[16], const float* src_xyz, siz
   std::memset(&hs, 0, sizeof(hs));
   std::memcpy(hs.T, T, sizeof(hs.T));
   hs.active = 1;
-  const int QB = nn_queries_per_block(ctx->nn_variant);
+  const int QB = ctx->nn_exhaustive ? nn_queries_per_block(ctx->nn_variant) : NNP_THREADS;
   const int qt = ((int)n_src + QB - 1) / QB, tiles = n_pad_t / NN_TILE;
   int sp = n_splits;
-  if (sp <= 0) {
+  if (!ctx->nn_exhaustive) {
+    sp = 1;
+  } else if (sp <= 0) {
     sp = 1;
     while ((long long)qt * sp < 1024 && sp < 64) sp *= 2;
   }
@@ -101,9 +122,14 @@ int lgicp_nn_search(lgicp_ctx* ctx, const float T[16], const float* src_xyz, siz
   HIP_TRY(ctx, hipMemcpy(d_pair, &hp, sizeof(hp), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(d_state, &hs, sizeof(hs), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(d_bmap, bmap.data(), sizeof(int4) * bmap.size(), hipMemcpyHostToDevice));
-  if (sp > 1) HIP_TRY(ctx, launch_keys_fill(d_pair, d_state, 1, (int)n_src, false, st));
-  HIP_TRY(ctx, launch_nn_search(d_clouds, d_pair, d_state, d_bmap, (int)bmap.size(), false, sp > 1,
-                                ctx->nn_variant, st));
+  if (!ctx->nn_exhaustive) {
+    HIP_TRY(ctx, launch_nn_pruned(d_clouds, d_pair, d_state, d_bmap, (int)bmap.size(), false,
+                                  __builtin_inff(), ctx->nn_r0sq, nullptr, st));
+  } else {
+    if (sp > 1) HIP_TRY(ctx, launch_keys_fill(d_pair, d_state, 1, (int)n_src, false, st));
+    HIP_TRY(ctx, launch_nn_search(d_clouds, d_pair, d_state, d_bmap, (int)bmap.size(), false,
+                                  sp > 1, ctx->nn_variant, st));
+  }
   HIP_TRY(ctx, launch_keys_unpack(d_keys, (int)n_src, d_idx, d_d2, st));
   HIP_TRY(ctx, hipMemcpyAsync(idx, d_idx, sizeof(int32_t) * n_src, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipMemcpyAsync(d2, d_d2, sizeof(float) * n_src, hipMemcpyDeviceToHost, st));

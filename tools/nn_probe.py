@@ -1,0 +1,34 @@
+"""Prints per-stage times and the executed/dense distance ratio of one C2 submit (GPU box)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from lamp_amd import capi, workload
+
+def main():
+    kw = {}
+    for a in sys.argv[1:]:
+        k, v = a.split("=")
+        kw[k] = int(v)
+    res = [0] * 8
+    res[2] = kw.pop("exhaustive", 0)
+    res[3] = kw.pop("r0mm", 0)
+    res[4] = kw.pop("capmm", 0)
+    iters = kw.pop("iters", 200)
+    n_pairs = kw.pop("pairs", 256)
+    wl = workload.Workload("C2", pairs=n_pairs)
+    c = capi.Context(init_method=capi.INIT_IDENTITY, iterations=iters, reserved=(capi.C.c_int * 8)(*res))
+    wl.register(c)
+    for rep in range(3):
+        t = time.time()
+        out = c.submit(wl.candidates())
+        dt = time.time() - t
+        s = c.stats()
+        print(json.dumps({"rep": rep, "wall_ms": 1e3 * dt, "nn_ms": s.nn_ms, "reduce_ms": s.reduce_ms,
+                          "solve_ms": s.solve_ms, "cov_ms": s.cov_ms, "total_ms": s.total_ms,
+                          "final_nn_ms": s.last_nn_kernel_ms,
+                          "dense_evals_per_pass": s.last_nn_evals_per_launch,
+                          "executed_evals": s.nn_executed_evals,
+                          "ok": sum(r.status == 0 for r in out)}))
+    c.close()
+
+main()
