@@ -309,56 +309,97 @@ __device__ void mat4f_mul(const float a[16], const float b[16], float out[16]) {
     }
 }
 
+// One wave per pair.  Every lane carries the same scalar state (x, f, Theta ...) and executes
+// the same control flow; the dense pieces of a Gauss-Newton step (Q d, Q J, J^T Q J, J^T g) are
+// spread over the lanes one output entry per lane, each entry summed in the same order a single
+// thread would use, and exchanged through LDS.
+struct SolveLds {
+  double stat[NSTAT + 2];
+  double Q[144];   // full symmetric 12 x 12
+  double b[12];
+  double s[12];    // Q d
+  double J[72];    // 12 x 6
+  double QJ[72];
+  double H[36];
+  double g[6];
+};
+
+// f(Theta) = c + d^T (2 b + Q d), d = Theta - Theta0; optionally the gradient wrt Theta
+__device__ double quad_eval_wave(SolveLds& L, const double Theta0[12], double c, const double Th[12],
+                                 double* grad12, int lane) {
+  double d[12];
+  for (int i = 0; i < 12; ++i) d[i] = Th[i] - Theta0[i];
+  __syncthreads();  // L.s may still be read from the previous evaluation
+  if (lane < 12) {
+    double acc = 0;
+    for (int j = 0; j < 12; ++j) acc += L.Q[lane * 12 + j] * d[j];
+    L.s[lane] = acc;
+  }
+  __syncthreads();
+  double f = c;
+  for (int i = 0; i < 12; ++i) {
+    const double si = L.s[i];
+    f += d[i] * (2.0 * L.b[i] + si);
+    if (grad12) grad12[i] = 2.0 * (L.b[i] + si);
+  }
+  return f;
+}
+
 __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restrict__ pairs,
                                                         PairState* __restrict__ st,
                                                         const int* __restrict__ n_chunks,
                                                         const double* __restrict__ partials,
                                                         SolveParams sp, int* __restrict__ n_done) {
-  __shared__ double stat[NSTAT + 6];
+  __shared__ SolveLds L;
   const int pair = blockIdx.x;
   PairState& S = st[pair];
   if (!S.active) return;
   const int lane = threadIdx.x;
-  for (int i = lane; i < NSTAT; i += 64) {
-    double s = 0;
+  {
     const int nc = n_chunks[pair];
-    for (int c = 0; c < nc; ++c) s += partials[((size_t)pair * RED_MAX_CHUNKS + c) * NSTAT + i];
-    stat[i] = s;
+    for (int i = lane; i < NSTAT; i += 64) {
+      double acc = 0;
+      for (int c = 0; c < nc; ++c) acc += partials[((size_t)pair * RED_MAX_CHUNKS + c) * NSTAT + i];
+      L.stat[i] = acc;
+    }
   }
   __syncthreads();
-  if (lane != 0) return;
 
   const PairDev& P = pairs[pair];
-  const int m = (int)(stat[NSTAT - 1] + 0.5);
-  S.m = m;
+  const int m = (int)(L.stat[NSTAT - 1] + 0.5);
   float T[16], Tprev[16];
   for (int i = 0; i < 16; ++i) T[i] = S.T[i];
   for (int i = 0; i < 16; ++i) Tprev[i] = T[i];  // previous_transformation_ = transformation_
   bool done = false;
+  bool failed = false, converged = false;
+  double delta = 0.;
+  int it_out = S.iterations;
+  unsigned long long h_prev = 0;
   if (m < 4) {
     // NotEnoughPointsException -> break out of the loop, converged_ stays false
     // (gicp.hpp:225-233, 542-547)
-    S.failed = 1;
-    S.converged = 0;
+    failed = true;
     done = true;
   } else {
-    QuadForm q;
-    // expand the 10 x 6 packed moments to the packed symmetric 12x12
-    for (int k = 0; k < 4; ++k)
-      for (int l = k; l < 4; ++l) {
-        const double* s6 = &stat[uu_slot(k, l) * 6];
-        const double Ms[9] = {s6[0], s6[1], s6[2], s6[1], s6[3], s6[4], s6[2], s6[4], s6[5]};
-        for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) {
-            const int i = k * 3 + a, j = l * 3 + b;
-            if (i <= j) q.Q[sym12(i, j)] = Ms[a * 3 + b];
-          }
-      }
-    for (int i = 0; i < 12; ++i) q.b[i] = stat[60 + i];
-    q.c = stat[72];
+    // expand the 10 x 6 packed moments to the full symmetric 12 x 12
+    for (int e = lane; e < 144; e += 64) {
+      const int i = e / 12, j = e % 12;
+      const int k = i / 3, a = i % 3, l = j / 3, bb = j % 3;
+      const int kk = k <= l ? k : l, ll = k <= l ? l : k;
+      const int aa = k <= l ? a : bb, b2 = k <= l ? bb : a;
+      const double* s6 = &L.stat[uu_slot(kk, ll) * 6];
+      const int lo = aa < b2 ? aa : b2, hi = aa < b2 ? b2 : aa;
+      // symmetric 3x3 stored as c00 c01 c02 c11 c12 c22
+      const int idx = lo == 0 ? hi : (lo == 1 ? 2 + hi : 5);
+      L.Q[e] = s6[idx];
+    }
+    if (lane < 12) L.b[lane] = L.stat[60 + lane];
+    __syncthreads();
+    const double qc = L.stat[72];
+    double Theta0[12];
     for (int k = 0; k < 3; ++k)
-      for (int a = 0; a < 3; ++a) q.Theta0[k * 3 + a] = (double)T[a * 4 + k];
-    for (int a = 0; a < 3; ++a) q.Theta0[9 + a] = (double)T[a * 4 + 3];
+      for (int a = 0; a < 3; ++a) Theta0[k * 3 + a] = (double)T[a * 4 + k];
+    for (int a = 0; a < 3; ++a) Theta0[9 + a] = (double)T[a * 4 + 3];
 
     double x[6];
     x[0] = T[3];
@@ -369,40 +410,48 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     x[5] = atan2((double)T[4], (double)T[0]);
     double Th[12], dTh[3][9], g12[12];
     theta_of_x(x, Th, dTh, true);
-    double f = quad_eval(q, Th, g12);
+    double f = quad_eval_wave(L, Theta0, qc, Th, g12, lane);
     for (int it = 0; it < sp.max_inner_iterations; ++it) {
-      double J[12][6];
-      for (int e = 0; e < 12; ++e)
-        for (int c = 0; c < 6; ++c) J[e][c] = 0.0;
-      for (int a = 0; a < 3; ++a) J[9 + a][a] = 1.0;
-      for (int c = 0; c < 3; ++c)
-        for (int e = 0; e < 9; ++e) J[e][3 + c] = dTh[c][e];
-      double g[6], H[36], QJ[12][6];
-      for (int c = 0; c < 6; ++c) {
-        double s = 0;
-        for (int e = 0; e < 12; ++e) s += J[e][c] * g12[e];
-        g[c] = -s;
+      __syncthreads();
+      for (int e = lane; e < 72; e += 64) {
+        const int r = e / 6, c = e % 6;
+        double v = 0.0;
+        if (c < 3)
+          v = (r == 9 + c) ? 1.0 : 0.0;
+        else if (r < 9)
+          v = dTh[c - 3][r];
+        L.J[e] = v;
       }
-      for (int e = 0; e < 12; ++e)
-        for (int c = 0; c < 6; ++c) {
-          double s = 0;
-          for (int e2 = 0; e2 < 12; ++e2) s += q.Q[sym12(e, e2)] * J[e2][c];
-          QJ[e][c] = s;
-        }
-      for (int c = 0; c < 6; ++c)
-        for (int c2 = 0; c2 < 6; ++c2) {
-          double s = 0;
-          for (int e = 0; e < 12; ++e) s += J[e][c] * QJ[e][c2];
-          H[c * 6 + c2] = 2.0 * s;
-        }
-      double dx[6];
+      __syncthreads();
+      if (lane < 6) {
+        double acc = 0;
+        for (int e = 0; e < 12; ++e) acc += L.J[e * 6 + lane] * g12[e];
+        L.g[lane] = -acc;
+      }
+      for (int e = lane; e < 72; e += 64) {
+        const int r = e / 6, c = e % 6;
+        double acc = 0;
+        for (int e2 = 0; e2 < 12; ++e2) acc += L.Q[r * 12 + e2] * L.J[e2 * 6 + c];
+        L.QJ[e] = acc;
+      }
+      __syncthreads();
+      if (lane < 36) {
+        const int c = lane / 6, c2 = lane % 6;
+        double acc = 0;
+        for (int e = 0; e < 12; ++e) acc += L.J[e * 6 + c] * L.QJ[e * 6 + c2];
+        L.H[lane] = 2.0 * acc;
+      }
+      __syncthreads();
+      double H[36], g[6], dx[6];
+      for (int i = 0; i < 36; ++i) H[i] = L.H[i];
+      for (int i = 0; i < 6; ++i) g[i] = L.g[i];
       if (!chol6_solve(H, g, dx)) break;
       double step = 1.0, fn = f, xn[6];
       bool ok = false;
       for (int h = 0; h < 30; ++h) {
         for (int c = 0; c < 6; ++c) xn[c] = x[c] + step * dx[c];
         theta_of_x(xn, Th, dTh, false);
-        fn = quad_eval(q, Th, nullptr);
+        fn = quad_eval_wave(L, Theta0, qc, Th, nullptr, lane);
         if (fn < f) {
           ok = true;
           break;
@@ -416,22 +465,18 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
         x[c] = xn[c];
       }
       theta_of_x(x, Th, dTh, true);
-      f = quad_eval(q, Th, g12);
+      f = quad_eval_wave(L, Theta0, qc, Th, g12, lane);
       if (mx < 1e-12) break;
     }
     apply_state(x, T);
     // convergence test (gicp.hpp:526-541, 564-580)
-    double delta = 0.;
     for (int k = 0; k < 4; ++k)
       for (int l = 0; l < 4; ++l) {
         const double ratio = (k < 3 && l < 3) ? 1. / sp.rotation_epsilon : 1. / sp.tf_epsilon;
         const double c_delta = ratio * fabs((double)(Tprev[k * 4 + l] - T[k * 4 + l]));
         if (c_delta > delta) delta = c_delta;
       }
-    S.delta = delta;
-    const int it = S.iterations + 1;
-    S.iterations = it;
-    for (int i = 0; i < 16; ++i) S.T[i] = T[i];
+    it_out = S.iterations + 1;
     // With tf_epsilon = 1e-10 the test delta < 1 asks for a bit-identical float translation;
     // the exact minimiser can instead settle into a short limit cycle in which one
     // correspondence flips and T alternates between float-adjacent matrices (periods 2 and 6
@@ -441,15 +486,28 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     bool cycle = false;
     {
       const unsigned long long h = hash_T(T);
-      const int n_hist = it - 1 < 16 ? it - 1 : 16;
+      const int n_hist = it_out - 1 < 16 ? it_out - 1 : 16;
       for (int k = 0; k < n_hist; ++k) cycle = cycle || (S.Thash[k] == h);
-      S.Thash[(it - 1) % 16] = hash_T(Tprev);
+      h_prev = hash_T(Tprev);
     }
-    if (it >= sp.max_iterations || delta < 1 || cycle) {
-      S.converged = 1;
+    if (it_out >= sp.max_iterations || delta < 1 || cycle) {
+      converged = true;
       for (int i = 0; i < 16; ++i) Tprev[i] = T[i];
       done = true;
     }
+  }
+  __syncthreads();  // every lane has read S before lane 0 rewrites it
+  if (lane != 0) return;
+  S.m = m;
+  if (failed) {
+    S.failed = 1;
+    S.converged = 0;
+  } else {
+    S.delta = delta;
+    S.iterations = it_out;
+    for (int i = 0; i < 16; ++i) S.T[i] = T[i];
+    S.Thash[(it_out - 1) % 16] = h_prev;
+    if (converged) S.converged = 1;
   }
   for (int i = 0; i < 16; ++i) S.Tprev[i] = Tprev[i];
   if (done) {

@@ -655,25 +655,30 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_ev, red_ev, sol_ev;
   std::vector<int> h_flags((size_t)n_pairs + 1, 0);
   int outer = 0, done_seen = 0;
+  // The host looks at the per-pair "done" flags only every `stride` iterations: kernels skip
+  // pairs that have left the loop on their own, so the iterations in between need no round trip.
+  // The exhaustive kernel's cost follows its grid, so it keeps the block maps tight instead.
+  const int stride = ctx->nn_exhaustive ? 1 : (cfg.reserved[5] > 0 ? cfg.reserved[5] : 1);
   while (!active.empty() && outer < cfg.iterations + 1) {
-    hipEvent_t a = ctx->event(), b = ctx->event(), c = ctx->event(), d = ctx->event();
-    HIP_TRY(ctx, hipEventRecord(a, st));
-    HIP_TRY(ctx, nn_pass(false));
-    HIP_TRY(ctx, hipEventRecord(b, st));
-    HIP_TRY(ctx, launch_gicp_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
-                                    ctx->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
-                                    ctx->d_partials.p, st));
-    HIP_TRY(ctx, hipEventRecord(c, st));
-    HIP_TRY(ctx, launch_gicp_solve(ctx->d_pairs.p, ctx->d_state.p, n_pairs, ctx->d_ints.p,
-                                   ctx->d_partials.p, sp, d_done, st));
-    HIP_TRY(ctx, hipEventRecord(d, st));
+    for (int rep = 0; rep < stride && outer < cfg.iterations + 1; ++rep, ++outer) {
+      hipEvent_t a = ctx->event(), b = ctx->event(), c = ctx->event(), d = ctx->event();
+      HIP_TRY(ctx, hipEventRecord(a, st));
+      HIP_TRY(ctx, nn_pass(false));
+      HIP_TRY(ctx, hipEventRecord(b, st));
+      HIP_TRY(ctx, launch_gicp_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
+                                      ctx->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
+                                      ctx->d_partials.p, st));
+      HIP_TRY(ctx, hipEventRecord(c, st));
+      HIP_TRY(ctx, launch_gicp_solve(ctx->d_pairs.p, ctx->d_state.p, n_pairs, ctx->d_ints.p,
+                                     ctx->d_partials.p, sp, d_done, st));
+      HIP_TRY(ctx, hipEventRecord(d, st));
+      nn_ev.emplace_back(a, b);
+      red_ev.emplace_back(b, c);
+      sol_ev.emplace_back(c, d);
+    }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_done, d_done, sizeof(int) * ((size_t)n_pairs + 1),
                                 hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    nn_ev.emplace_back(a, b);
-    red_ev.emplace_back(b, c);
-    sol_ev.emplace_back(c, d);
-    ++outer;
     if (ctx->h_done[0] != done_seen) {
       done_seen = ctx->h_done[0];
       active.clear();
