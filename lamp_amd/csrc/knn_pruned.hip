@@ -7,9 +7,9 @@
 // among exactly equidistant targets.  What changes is how much of the target is looked at.
 //
 // Layout.  Every cloud carries a spatial index built once (spatial_index.hip): its points in
-// Morton order cut into tiles of SI_TILE points, each point stored with its original index,
-// plus the axis-aligned box of every tile and the Morton visiting order of the cloud's own
-// points.  One wave owns 64 Morton-consecutive queries — a compact patch of surface — and keeps
+// k-d partition order cut into tiles of SI_TILE points, each point stored with its original index,
+// plus the axis-aligned box of every tile and the same visiting order of the cloud's own
+// points.  One wave owns 64 consecutive queries of that order — a compact patch of surface — and keeps
 // the patch's box.  The float box-to-box gap, squared and summed in the same operation order as
 // a point distance, never exceeds the computed distance of any query/target pair drawn from
 // the two boxes (rounding is monotonic), so a tile whose gap exceeds every lane's current best
@@ -73,7 +73,7 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
     const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
     const PairState* __restrict__ st, const int4* __restrict__ bmap, int final_pass, float cap,
-    float r0sq, unsigned long long* __restrict__ counters) {
+    float r0sq, int use_seed, unsigned long long* __restrict__ counters) {
   const int4 bm = bmap[blockIdx.x];
   const int pair = bm.x;
   const PairState& S = st[pair];
@@ -115,6 +115,20 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
   float bestd = __builtin_inff();  // smallest finite distance so far
   int bgrp = -1;                   // first group (tile * 4 + k) that reached it
   bool tie = false;                // another group reached exactly the same distance
+  // Seed: the match of the previous pass, re-measured under the current transformation, is an
+  // upper bound of this pass's nearest distance.  Tiles that cannot reach it are then dropped by
+  // the per-lane test before any of their points is looked at.  The seed's own tile always
+  // passes that test, so the sweep re-finds the seed (or something at least as close) itself.
+  if (use_seed && finite) {
+    const nnkey_t prev = P.keys[qi];
+    const unsigned pi = (unsigned)(prev & 0xFFFFFFFFu);
+    if (prev != NNKEY_NONE && pi < (unsigned)TG.n) {
+      const float4 p = TG.xyz[pi];
+      const float dx = x - p.x, dy = y - p.y, dz = z - p.z;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      if (d <= cap) bestd = d;  // false for NaN
+    }
+  }
   unsigned visited = 0;
   float lo = -1.0f, hi = __builtin_fminf(r0sq, cap);
   float worst = __builtin_inff();  // wave-uniform: max over finite lanes of bestd, per round
@@ -162,7 +176,8 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
             m = __builtin_fminf(__builtin_fminf(m, d.x), d.y);
           }
           // +inf and NaN distances (padding, overflow) never count
-          const bool lower = m < bestd;
+          // a seeded bound counts as reached by the first group that equals it
+          const bool lower = m < bestd || (m == bestd && bgrp < 0);
           tie = lower ? false : (tie || m == bestd);
           bestd = lower ? m : bestd;
           bgrp = lower ? tile * (SI_TILE / GROUP) + g : bgrp;
@@ -234,10 +249,10 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
 
 hipError_t launch_nn_pruned(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
                             const int4* bmap, int n_blocks, bool final_pass, float cap, float r0sq,
-                            unsigned long long* counters, hipStream_t stream) {
+                            bool use_seed, unsigned long long* counters, hipStream_t stream) {
   if (n_blocks <= 0) return hipSuccess;
   hipLaunchKernelGGL(nn_pruned_kernel, dim3(n_blocks), dim3(NNP_THREADS), 0, stream, clouds, pairs,
-                     st, bmap, (int)final_pass, cap, r0sq, counters);
+                     st, bmap, (int)final_pass, cap, r0sq, (int)use_seed, counters);
   return hipGetLastError();
 }
 

@@ -72,13 +72,13 @@ void xcd_permute(std::vector<T>& v) {
 
 namespace lgicp_detail {
 
-// Morton order on the host, tiles and boxes on the device; the cloud is one segment.
+// k-d visiting order on the host, tiles and boxes on the device; the cloud is one segment.
 int build_keyframe_index(lgicp_ctx* ctx, Keyframe* kf, const float* xyz, size_t stride_floats) {
   const int n = kf->n;
   kf->n_tiles = (n + SI_TILE - 1) / SI_TILE;
   kf->n_q = round_up(n, 64);
   if (n == 0) return LGICP_OK;
-  const std::vector<int> order = si::morton_order(xyz, (size_t)n, stride_floats);
+  const std::vector<int> order = si::kd_order(xyz, (size_t)n, stride_floats, SI_TILE);
   HIP_TRY(ctx, hipMalloc((void**)&kf->d_order, sizeof(int) * (size_t)n));
   HIP_TRY(ctx, hipMalloc((void**)&kf->d_sxyz, sizeof(float4) * (size_t)kf->n_tiles * SI_TILE));
   HIP_TRY(ctx, hipMalloc((void**)&kf->d_tmin, sizeof(float4) * (size_t)kf->n_tiles));
@@ -168,6 +168,7 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
     ctx->nn_r0sq = r0 * r0;
   }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->flag_stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_done, sizeof(int) * 65536, hipHostMallocDefault) != hipSuccess) {
     delete ctx;
     return fail(nullptr, LGICP_E_HIP, "stream / pinned allocation failed");
@@ -190,6 +191,9 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   ctx->d_segs.release();
   ctx->d_bmap_nn.release();
   ctx->d_bmap_red.release();
+  ctx->d_bmap_nn_all.release();
+  ctx->d_bmap_red_all.release();
+  if (ctx->flag_stream) (void)hipStreamDestroy(ctx->flag_stream);
   ctx->d_ints.release();
   ctx->d_partials.release();
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -530,6 +534,15 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
                               hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
                               sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
+  // the pass after the loop covers every pair again: its maps stay resident beside the live ones
+  const int n_all_nn = (int)h_bmap_nn.size(), n_all_red = (int)h_bmap_red.size();
+  const bool all_split = any_split;
+  HIP_TRY(ctx, ctx->d_bmap_nn_all.reserve(h_bmap_nn.size()));
+  HIP_TRY(ctx, ctx->d_bmap_red_all.reserve(h_bmap_red.size()));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn_all.p, h_bmap_nn.data(),
+                              sizeof(int4) * h_bmap_nn.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red_all.p, h_bmap_red.data(),
+                              sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ints.p, h_ints.data(), sizeof(int) * h_ints.size(),
                               hipMemcpyHostToDevice, st));
   // the host vectors above must outlive the copies
@@ -546,6 +559,8 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
       HIP_TRY(ctx, launch_pad_fill(const_cast<float4*>(h_clouds[c].xyz), h_clouds[c].n,
                                    h_clouds[c].n_pad, st));
   HIP_TRY(ctx, launch_index_fill(ctx->d_isegs.p, (int)h_isegs.size(), max_iseg_n, st));
+  // no previous match to seed the first lookup with
+  HIP_TRY(ctx, launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, true, st));
   if (cfg.covariance_from_knn) {
     for (int c = 0; c < n_clouds; ++c)
       HIP_TRY(ctx, launch_cov_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
@@ -628,17 +643,20 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   if (cfg.reserved[4] > 0)  // diagnostics only: a smaller cap drops correspondences
     nn_cap = 1e-6f * (float)cfg.reserved[4] * (float)cfg.reserved[4];
   auto nn_pass = [&](bool final_pass) -> hipError_t {
+    const int4* map = final_pass ? ctx->d_bmap_nn_all.p : ctx->d_bmap_nn.p;
+    const int n_map = final_pass ? n_all_nn : (int)h_bmap_nn.size();
+    const bool split = final_pass ? all_split : any_split;
     if (!ctx->nn_exhaustive)
-      return launch_nn_pruned(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, ctx->d_bmap_nn.p,
-                              (int)h_bmap_nn.size(), final_pass,
+      return launch_nn_pruned(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, map, n_map,
+                              final_pass,
                               final_pass ? std::numeric_limits<float>::infinity() : nn_cap,
-                              ctx->nn_r0sq, ctx->d_counters.p, st);
-    if (any_split) {
+                              ctx->nn_r0sq, cfg.reserved[6] != 1, ctx->d_counters.p, st);
+    if (split) {
       hipError_t e = launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, final_pass, st);
       if (e != hipSuccess) return e;
     }
-    return launch_nn_search(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, ctx->d_bmap_nn.p,
-                            (int)h_bmap_nn.size(), final_pass, any_split, ctx->nn_variant, st);
+    return launch_nn_search(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, map, n_map,
+                            final_pass, split, ctx->nn_variant, st);
   };
   std::vector<int> active;
   for (int p = 0; p < n_pairs; ++p)
@@ -655,59 +673,96 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_ev, red_ev, sol_ev;
   std::vector<int> h_flags((size_t)n_pairs + 1, 0);
   int outer = 0, done_seen = 0;
-  // The host looks at the per-pair "done" flags only every `stride` iterations: kernels skip
-  // pairs that have left the loop on their own, so the iterations in between need no round trip.
-  // The exhaustive kernel's cost follows its grid, so it keeps the block maps tight instead.
-  const int stride = ctx->nn_exhaustive ? 1 : (cfg.reserved[5] > 0 ? cfg.reserved[5] : 1);
-  while (!active.empty() && outer < cfg.iterations + 1) {
-    for (int rep = 0; rep < stride && outer < cfg.iterations + 1; ++rep, ++outer) {
-      hipEvent_t a = ctx->event(), b = ctx->event(), c = ctx->event(), d = ctx->event();
-      HIP_TRY(ctx, hipEventRecord(a, st));
-      HIP_TRY(ctx, nn_pass(false));
-      HIP_TRY(ctx, hipEventRecord(b, st));
-      HIP_TRY(ctx, launch_gicp_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
-                                      ctx->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
-                                      ctx->d_partials.p, st));
-      HIP_TRY(ctx, hipEventRecord(c, st));
-      HIP_TRY(ctx, launch_gicp_solve(ctx->d_pairs.p, ctx->d_state.p, n_pairs, ctx->d_ints.p,
-                                     ctx->d_partials.p, sp, d_done, st));
-      HIP_TRY(ctx, hipEventRecord(d, st));
-      nn_ev.emplace_back(a, b);
-      red_ev.emplace_back(b, c);
-      sol_ev.emplace_back(c, d);
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_done, d_done, sizeof(int) * ((size_t)n_pairs + 1),
-                                hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (ctx->h_done[0] != done_seen) {
-      done_seen = ctx->h_done[0];
-      active.clear();
-      for (int p = 0; p < n_pairs; ++p)
-        if (h_state[p].active && !ctx->h_done[1 + p]) active.push_back(p);
-      if (!active.empty()) {
-        build_maps(active);
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, h_bmap_nn.data(),
-                                    sizeof(int4) * h_bmap_nn.size(), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
-                                    sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<int4> stage_nn[2], stage_red[2];
+  int stage_k = 0;
+  // The host stays one iteration behind the device: iteration i+1 is enqueued before the
+  // "done" flags of iteration i are looked at, so the device never waits for the round trip.
+  // Pairs that have left the loop are skipped by the kernels themselves (PairState::active);
+  // the block maps only follow, two iterations late, to keep the grids small.
+  hipEvent_t flag_ev[2] = {ctx->event(), ctx->event()};
+  int* h_flags2[2] = {ctx->h_done, ctx->h_done + 32768};
+  auto enqueue_iteration = [&](int slot) -> int {
+    hipEvent_t a = ctx->event(), b = ctx->event(), c = ctx->event(), d = ctx->event();
+    HIP_TRY(ctx, hipEventRecord(a, st));
+    HIP_TRY(ctx, nn_pass(false));
+    HIP_TRY(ctx, hipEventRecord(b, st));
+    HIP_TRY(ctx, launch_gicp_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
+                                    ctx->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
+                                    ctx->d_partials.p, st));
+    HIP_TRY(ctx, hipEventRecord(c, st));
+    HIP_TRY(ctx, launch_gicp_solve(ctx->d_pairs.p, ctx->d_state.p, n_pairs, ctx->d_ints.p,
+                                   ctx->d_partials.p, sp, d_done, st));
+    HIP_TRY(ctx, hipEventRecord(d, st));
+    // the flags travel on their own stream: the next iteration does not queue up behind the copy
+    // (a copy that overlaps the next solve kernel can only see more pairs done, never fewer)
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->flag_stream, d, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(h_flags2[slot], d_done, sizeof(int) * ((size_t)n_pairs + 1),
+                                hipMemcpyDeviceToHost, ctx->flag_stream));
+    HIP_TRY(ctx, hipEventRecord(flag_ev[slot], ctx->flag_stream));
+    nn_ev.emplace_back(a, b);
+    red_ev.emplace_back(b, c);
+    sol_ev.emplace_back(c, d);
+    return LGICP_OK;
+  };
+  const int n_active0 = (int)active.size();
+  const bool lagged = !ctx->nn_exhaustive && cfg.reserved[5] != 1;
+  if (!active.empty()) {
+    int rc = enqueue_iteration(0);
+    if (rc != LGICP_OK) return rc;
+    outer = 1;
+    for (;;) {
+      const int prev = (outer - 1) & 1;
+      bool enqueued = false;
+      if (lagged && outer < cfg.iterations + 1) {
+        rc = enqueue_iteration(outer & 1);
+        if (rc != LGICP_OK) return rc;
+        enqueued = true;
+      }
+      HIP_TRY(ctx, hipEventSynchronize(flag_ev[prev]));
+      const int* flags = h_flags2[prev];
+      const bool all_done = flags[0] >= n_active0;
+      if (enqueued) ++outer;
+      if (all_done || outer >= cfg.iterations + 1) {
+        if (enqueued) HIP_TRY(ctx, hipStreamSynchronize(st));  // kernels found nothing to do
+        break;
+      }
+      if (flags[0] != done_seen) {
+        done_seen = flags[0];
+        active.clear();
+        for (int p = 0; p < n_pairs; ++p)
+          if (h_state[p].active && !flags[1 + p]) active.push_back(p);
+        if (!active.empty()) {
+          build_maps(active);
+          // Staged through two alternating host copies: an upload is followed in the stream by
+          // the next iteration's flag event, which the host has waited for before the same
+          // staging copy is written again.
+          std::vector<int4>& s_nn = stage_nn[stage_k];
+          std::vector<int4>& s_red = stage_red[stage_k];
+          stage_k ^= 1;
+          s_nn = h_bmap_nn;
+          s_red = h_bmap_red;
+          HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, s_nn.data(), sizeof(int4) * s_nn.size(),
+                                      hipMemcpyHostToDevice, st));
+          HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, s_red.data(), sizeof(int4) * s_red.size(),
+                                      hipMemcpyHostToDevice, st));
+        }
+      }
+      if (!enqueued) {
+        rc = enqueue_iteration(outer & 1);
+        if (rc != LGICP_OK) return rc;
+        ++outer;
       }
     }
   }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->flag_stream));
 
   // ---- final pass: fitness + correspondences + Ap ----------------------------------------------
-  build_maps(all_pairs);
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size(),
-                              hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
-                              sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
   hipEvent_t ev_post0 = ctx->event(), ev_post1 = ctx->event(), ev_post2 = ctx->event();
   HIP_TRY(ctx, hipEventRecord(ev_post0, st));
   HIP_TRY(ctx, nn_pass(true));
   HIP_TRY(ctx, hipEventRecord(ev_post1, st));
   HIP_TRY(ctx, launch_post_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
-                                  ctx->d_bmap_red.p, (int)h_bmap_red.size(), ctx->d_partials.p,
+                                  ctx->d_bmap_red_all.p, n_all_red, ctx->d_partials.p,
                                   cfg.covariance_method == LGICP_COV_POINT2POINT &&
                                       !cfg.use_fixed_covariances,
                                   st));
@@ -868,7 +923,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
       }
       const size_t est = (size_t)ctx->scans.at(c.key_from).n * 24 * (cfg.accumulate_source ? 5 : 1);
       if (!bp.pairs.empty() &&
-          (bp.bytes + pair_bytes + est > cfg.workspace_bytes || bp.pairs.size() >= 32768))
+          (bp.bytes + pair_bytes + est > cfg.workspace_bytes || bp.pairs.size() >= 32767))
         break;
       PairPlan pp;
       pp.cand = i;

@@ -20,7 +20,7 @@ static constexpr int NN_THREADS = 256;
 static constexpr int NN_TILE = 1024;  // target points per LDS tile (12 KiB as SoA floats)
 static constexpr int NN_GROUP = 8;    // targets whose minimum is tracked together
 
-// spatial index of a cloud: Morton-ordered points in tiles of SI_TILE with one box per tile
+// spatial index of a cloud: points in k-d partition order, in tiles of SI_TILE with one box per tile
 static constexpr int SI_TILE = 32;
 static constexpr int NNP_THREADS = 64;   // one wave of 64 queries per workgroup: waves finish independently
 static constexpr int NN_COUNTER_SLOTS = 4096;  // the evaluated-distance counter is spread over these
@@ -41,12 +41,12 @@ struct CloudDev {
   int n;
   int n_pad;
   // spatial index (spatial_index.hip)
-  const float4* sxyz;  // n_tiles tiles of SI_TILE points in Morton order, each tile stored as
+  const float4* sxyz;  // n_tiles tiles of SI_TILE points in k-d partition order, each tile stored as
                        // x[SI_TILE] y[SI_TILE] z[SI_TILE] original-index[SI_TILE]; unused
                        // slots hold +inf coordinates and index -1
   const float4* tmin;  // n_tiles box corners
   const float4* tmax;
-  const int* qorder;   // n_q original indices in Morton order, -1 in the padding
+  const int* qorder;   // n_q original indices in visiting order, -1 in the padding
   int n_tiles;
   int n_q;             // n rounded up to a multiple of 64
   // NormalizePCloud constants (used only for the un-accumulated source keyframe)
@@ -117,17 +117,18 @@ int nn_queries_per_block(int variant);
 
 // pruned exact 1-NN (knn_pruned.hip).  bmap entry: x = pair, y = group of NNP_THREADS queries.
 // cap = squared radius beyond which matches are not needed (+inf: exact for every query),
-// r0sq = squared radius of the first round; distances evaluated are added into
+// r0sq = squared radius of the first round; use_seed: PairDev::keys holds the previous pass's
+// result (or NNKEY_NONE) and bounds the search; distances evaluated are added into
 // counters[0 .. NN_COUNTER_SLOTS) (sum them)
 hipError_t launch_nn_pruned(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
                             const int4* bmap, int n_blocks, bool final_pass, float cap, float r0sq,
-                            unsigned long long* counters, hipStream_t stream);
+                            bool use_seed, unsigned long long* counters, hipStream_t stream);
 
 // One segment of a cloud's spatial index: n points of `xyz + point_off` visited in `order`
 // (a permutation of 0..n-1) fill tiles tile_off.. of the cloud's index arrays.
 struct IndexSegDev {
   const float4* xyz;   // the cloud's points in original order
-  const int* order;    // Morton order of this segment's own points
+  const int* order;    // visiting order of this segment's own points
   float4* sxyz;
   float4* tmin;
   float4* tmax;

@@ -27,7 +27,7 @@ struct Keyframe {
   // spatial index of the keyframe on its own (see CloudDev)
   int n_tiles = 0;
   int n_q = 0;
-  int* d_order = nullptr;   // n: Morton visiting order
+  int* d_order = nullptr;   // n: visiting order (k-d partition)
   float4* d_sxyz = nullptr;
   float4* d_tmin = nullptr;
   float4* d_tmax = nullptr;
@@ -80,7 +80,9 @@ struct lgicp_ctx {
   DevBuf<PairDev> d_pairs;
   DevBuf<PairState> d_state;
   DevBuf<SegmentDev> d_segs;
-  DevBuf<int4> d_bmap_nn, d_bmap_red;
+  DevBuf<int4> d_bmap_nn, d_bmap_red;          // block maps of the pairs still in the loop
+  DevBuf<int4> d_bmap_nn_all, d_bmap_red_all;  // block maps of every pair of the batch
+  hipStream_t flag_stream = nullptr;            // carries the "done" flags back to the host
   DevBuf<int> d_ints;  // n_chunks[n_pairs] | scan1 ids | n_done
   DevBuf<double> d_partials;
   DevBuf<IndexSegDev> d_isegs;

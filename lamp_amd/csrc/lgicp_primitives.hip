@@ -124,7 +124,7 @@ int lgicp_nn_search(lgicp_ctx* ctx, const float T[16], const float* src_xyz, siz
   HIP_TRY(ctx, hipMemcpy(d_bmap, bmap.data(), sizeof(int4) * bmap.size(), hipMemcpyHostToDevice));
   if (!ctx->nn_exhaustive) {
     HIP_TRY(ctx, launch_nn_pruned(d_clouds, d_pair, d_state, d_bmap, (int)bmap.size(), false,
-                                  __builtin_inff(), ctx->nn_r0sq, nullptr, st));
+                                  __builtin_inff(), ctx->nn_r0sq, false, nullptr, st));
   } else {
     if (sp > 1) HIP_TRY(ctx, launch_keys_fill(d_pair, d_state, 1, (int)n_src, false, st));
     HIP_TRY(ctx, launch_nn_search(d_clouds, d_pair, d_state, d_bmap, (int)bmap.size(), false,

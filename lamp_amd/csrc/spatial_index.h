@@ -42,5 +42,53 @@ inline std::vector<int> morton_order(const float* xyz, size_t n, size_t stride) 
   return order;
 }
 
+// Visiting order from a balanced k-d partition: the index range is halved at a tile boundary
+// along the longest axis of its points' box (median split) until a range holds one tile.
+// Consecutive runs of `leaf` points are then spatially compact with nearly disjoint boxes, and so
+// are the runs of 2 * leaf, 4 * leaf ... points above them.  Non-finite points go last.
+// Deterministic: ties along the split axis are ordered by index.
+inline std::vector<int> kd_order(const float* xyz, size_t n, size_t stride, int leaf) {
+  std::vector<int> order;
+  order.reserve(n);
+  std::vector<int> tail;
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = xyz + i * stride;
+    if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))
+      order.push_back((int)i);
+    else
+      tail.push_back((int)i);
+  }
+  struct Range {
+    size_t lo, hi;
+  };
+  std::vector<Range> stack;
+  if (!order.empty()) stack.push_back({0, order.size()});
+  while (!stack.empty()) {
+    const Range r = stack.back();
+    stack.pop_back();
+    const size_t m = r.hi - r.lo;
+    if (m <= (size_t)leaf) continue;
+    float lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = r.lo; i < r.hi; ++i) {
+      const float* p = xyz + (size_t)order[i] * stride;
+      for (int a = 0; a < 3; ++a) lo3[a] = std::min(lo3[a], p[a]), hi3[a] = std::max(hi3[a], p[a]);
+    }
+    int ax = 0;
+    for (int a = 1; a < 3; ++a)
+      if (hi3[a] - lo3[a] > hi3[ax] - lo3[ax]) ax = a;
+    const size_t tiles = (m + leaf - 1) / leaf;
+    const size_t k = (tiles / 2) * (size_t)leaf;  // left half: whole tiles
+    std::nth_element(order.begin() + r.lo, order.begin() + r.lo + k, order.begin() + r.hi,
+                     [&](int a, int b) {
+                       const float va = xyz[(size_t)a * stride + ax], vb = xyz[(size_t)b * stride + ax];
+                       return va < vb || (va == vb && a < b);
+                     });
+    stack.push_back({r.lo, r.lo + k});
+    stack.push_back({r.lo + k, r.hi});
+  }
+  order.insert(order.end(), tail.begin(), tail.end());
+  return order;
+}
+
 }  // namespace si
 }  // namespace lgicp
