@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X vector FP32 peak (packed FMA), per GPU
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, per GPU
 
 def pmc_traffic(kernel, config):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary of this same
@@ -76,6 +77,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--nn-variant", type=int, default=0)
+    ap.add_argument("--exhaustive", action="store_true",
+                    help="use the exhaustive 1-NN kernel instead of the pruned one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,9 +102,12 @@ def main():
     cfg = capi.default_config(True, device=local_rank, init_method=capi.INIT_IDENTITY)
     if args.nn_variant:
         cfg.reserved[0] = args.nn_variant
+    if args.exhaustive:
+        cfg.reserved[2] = 1
     ctx = capi.Context(cfg)
     work.register(ctx)                      # keyframes + poses resident in HBM before timing
     cands = work.candidates()
+    packed = ctx.pack_candidates(cands)     # the lgicp_candidate array a C++ caller hands over
 
     def barrier():
         if dist is not None:
@@ -110,7 +116,8 @@ def main():
             dist.barrier()
 
     def step():
-        res = ctx.submit(cands)             # blocking: returns after the device work is done
+        out = ctx.submit_packed(packed)     # blocking: returns after the device work is done
+        res = [out[i] for i in range(len(cands))]
         if dist is not None:
             import torch
             gather_records(pack_results(res), dist, rank, world, torch.device("cuda", local_rank))
@@ -119,7 +126,8 @@ def main():
 
     for _ in range(args.warmup):
         res = step()
-    nn_ms = nn_launches = nn_evals = 0.0
+    nn_ms = nn_launches = nn_evals = nn_exec = 0.0
+    red_ms = red_launches = red_points = red_inliers = 0.0
     stage = dict(nn=0.0, reduce=0.0, solve=0.0, cov=0.0, post=0.0, total=0.0)
     barrier()
     t0 = time.perf_counter()
@@ -130,6 +138,11 @@ def main():
         nn_ms += s1.nn_ms
         nn_launches += s1.nn_launches - s0.nn_launches
         nn_evals += s1.nn_distance_evals - s0.nn_distance_evals
+        nn_exec += s1.nn_executed_evals
+        red_ms += s1.reduce_ms
+        red_launches += s1.reduce_launches
+        red_points += s1.reduce_points
+        red_inliers += s1.reduce_inliers
         for k in stage:
             stage[k] += getattr(s1, k + "_ms")
     barrier()
@@ -155,6 +168,14 @@ def main():
         avg_launch_ms = nn_ms / max(nn_launches, 1)
         flops_per_launch = 8.0 * nn_evals / max(nn_launches, 1)
         achieved = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        exec_flops_per_launch = 8.0 * nn_exec / max(nn_launches, 1)
+        exec_achieved = (exec_flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
+                         if avg_launch_ms > 0 else 0.0)
+        kernel_name = ("lgicp::nn_kernel<4>" if cfg.reserved[2] == 1 else "lgicp::nn_pruned_kernel")
+        if cfg.reserved[2] == 1:
+            exec_flops_per_launch, exec_achieved = flops_per_launch, achieved
+        red_bytes = 44.0 * red_points + 40.0 * red_inliers
+        red_gbs = red_bytes / (red_ms * 1e-3) / 1e9 if red_ms > 0 else 0.0
         out = {
             "metric": "loop-closure GICP pairs verified/sec",
             "value": value,
@@ -187,17 +208,38 @@ def main():
             },
             "roofline": {
                 "bound": "fp32_valu",
-                "kernel": "lgicp::nn_kernel (tiled exhaustive 1-NN)",
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS,
-                "traffic": pmc_traffic("lgicp::nn_kernel<4>", args.config),
+                "traffic": pmc_traffic(kernel_name, args.config),
                 "avg_launch_ms": avg_launch_ms,
                 "launches_per_step": nn_launches / args.steps,
                 "flops_per_launch": flops_per_launch,
-                "note": "8 flop per query-target distance (3 sub, 3 mul, 2 add), unfused by "
-                        "contract; the 157.3 TFLOP/s peak assumes packed FMA",
+                "executed_flops_per_launch": exec_flops_per_launch,
+                "executed_achieved": exec_achieved,
+                "executed_frac": exec_achieved / FP32_VALU_PEAK_TFLOPS,
+                "note": "achieved = algorithmic work / time: 8 flop (3 sub, 3 mul, 2 add, unfused "
+                        "by contract) for each of the N*M query-target distances of every lookup "
+                        "pass; the 157.3 TFLOP/s peak assumes packed FMA.  The pruned kernel "
+                        "returns the same indices while evaluating only the distances its box "
+                        "tests cannot rule out, so achieved may exceed the peak; executed_* count "
+                        "the distances it really evaluated (device counter).",
+            },
+            "roofline_reduce": {
+                "bound": "hbm",
+                "kernel": "lgicp::gicp_reduce_kernel",
+                "achieved": red_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": red_gbs / HBM_PEAK_GBS,
+                "traffic": pmc_traffic("lgicp::gicp_reduce_kernel", args.config),
+                "avg_launch_ms": red_ms / max(red_launches, 1),
+                "bytes_per_launch": red_bytes / max(red_launches, 1),
+                "note": "algorithmic bytes: 44 B per source point read (16 p + 4 index + 24 C1) "
+                        "+ 40 B per correspondence inside corr_dist (16 q + 24 C2), f32 minimum "
+                        "layout; the kernel keeps covariances in f64 (the reference's type)",
             },
         }
         if not args.no_cpu and world == 1:

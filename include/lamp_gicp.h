@@ -150,6 +150,10 @@ typedef struct lgicp_stats {
   double last_nn_kernel_ms;     /* average duration of one 1-NN launch in the last submit */
   double last_nn_evals_per_launch;
   double nn_executed_evals;     /* distances the pruned 1-NN kernel actually evaluated, last submit */
+  double reduce_points;         /* source points read by the linearise/reduce kernel, summed over
+                                   pairs and outer iterations, last submit */
+  double reduce_inliers;        /* correspondences inside corr_dist among them */
+  uint64_t reduce_launches;     /* launches of the linearise/reduce kernel, last submit */
 } lgicp_stats;
 
 typedef struct lgicp_ctx lgicp_ctx;

@@ -62,7 +62,9 @@ class Stats(C.Structure):
                 ("nn_distance_evals", C.c_double), ("nn_ms", C.c_double), ("reduce_ms", C.c_double),
                 ("solve_ms", C.c_double), ("cov_ms", C.c_double), ("post_ms", C.c_double),
                 ("total_ms", C.c_double), ("last_nn_kernel_ms", C.c_double),
-                ("last_nn_evals_per_launch", C.c_double), ("nn_executed_evals", C.c_double)]
+                ("last_nn_evals_per_launch", C.c_double), ("nn_executed_evals", C.c_double),
+                ("reduce_points", C.c_double), ("reduce_inliers", C.c_double),
+                ("reduce_launches", C.c_uint64)]
 
 
 class LgicpError(RuntimeError):
@@ -177,6 +179,26 @@ class Context:
 
     def has_pose(self, key):
         return bool(lib().lgicp_has_pose(self._h, key))
+
+    def pack_candidates(self, candidates):
+        """The lgicp_candidate array a C++ caller would hand over as is."""
+        n = len(candidates)
+        arr = (Candidate * max(n, 1))()
+        for i, c in enumerate(candidates):
+            arr[i].key_from, arr[i].key_to = c[0], c[1]
+            pf = c[2] if len(c) > 2 else ((1, 0, 0, 0), (0, 0, 0))
+            pt = c[3] if len(c) > 3 else ((1, 0, 0, 0), (0, 0, 0))
+            arr[i].pose_from_q[:] = pf[0]
+            arr[i].pose_from_t[:] = pf[1]
+            arr[i].pose_to_q[:] = pt[0]
+            arr[i].pose_to_t[:] = pt[1]
+        return arr, n, (Result * max(n, 1))()
+
+    def submit_packed(self, packed):
+        """lgicp_submit on arrays from pack_candidates; returns the lgicp_result array."""
+        arr, n, out = packed
+        self._check(lib().lgicp_submit(self._h, arr, n, out))
+        return out
 
     def submit(self, candidates):
         """candidates: list of (key_from, key_to[, pose_from(q,t), pose_to(q,t)])"""

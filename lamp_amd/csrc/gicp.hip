@@ -30,10 +30,13 @@ __host__ __device__ constexpr int uu_slot(int k, int l) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
+__global__ __launch_bounds__(RED_THREADS, 2) void gicp_reduce_kernel(
     const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
     const PairState* __restrict__ st, const int4* __restrict__ bmap, double corr_dist2,
     double* __restrict__ partials) {
+  // double-precision statistics: no float result of the reference is reproduced bit by bit
+  // here, so multiply-adds may fuse (the float transformation arithmetic lives elsewhere)
+#pragma clang fp contract(fast)
   __shared__ double sh[RED_THREADS / 64][NSTAT];
   const int4 bm = bmap[blockIdx.x];
   const int pair = bm.x;
@@ -499,6 +502,7 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
   __syncthreads();  // every lane has read S before lane 0 rewrites it
   if (lane != 0) return;
   S.m = m;
+  S.m_sum += (double)m;
   if (failed) {
     S.failed = 1;
     S.converged = 0;

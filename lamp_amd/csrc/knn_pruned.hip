@@ -130,8 +130,11 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
     }
   }
   unsigned visited = 0;
-  float lo = -1.0f, hi = __builtin_fminf(r0sq, cap);
-  float worst = __builtin_inff();  // wave-uniform: max over finite lanes of bestd, per round
+  // wave-uniform: max over finite lanes of bestd, refreshed after every round.  With every lane
+  // seeded the first round already reaches as far as any lane can need.
+  float worst = wave_max_nonneg(finite ? bestd : 0.f);
+  float lo = -1.0f;
+  float hi = __builtin_fminf(worst < __builtin_inff() ? __builtin_fmaxf(r0sq, worst) : r0sq, cap);
   const int n_steps = (n_tiles + 63) / 64;
 
   for (;;) {

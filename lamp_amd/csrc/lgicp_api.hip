@@ -801,7 +801,8 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   S.post_ms += ms;
   (void)hipEventElapsedTime(&ms, ev_begin, ev_post2);
   S.total_ms += ms;
-  S.nn_launches += (uint64_t)outer + 1;
+  S.nn_launches += (uint64_t)nn_ev.size() + 1;
+  S.reduce_launches += (uint64_t)red_ev.size();
   // the final pass always covers every pair of the batch: it is the launch the roofline uses
   S.last_nn_kernel_ms = nn_final_ms;
   S.last_nn_evals_per_launch = evals_per_pass;
@@ -821,6 +822,8 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
       continue;
     }
     S.outer_iterations += (uint64_t)s.iterations;
+    S.reduce_points += (double)h_pairs[p].n_src * (double)s.iterations;
+    S.reduce_inliers += s.m_sum;
     S.nn_distance_evals +=
         (double)h_pairs[p].n_src * (double)h_pairs[p].n_tgt * (double)(s.iterations + 1);
     double post[NPOST] = {0};
@@ -896,6 +899,8 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   ctx->stats.nn_ms = ctx->stats.reduce_ms = ctx->stats.solve_ms = ctx->stats.cov_ms =
       ctx->stats.post_ms = ctx->stats.total_ms = 0;
   ctx->stats.nn_executed_evals = 0;
+  ctx->stats.reduce_points = ctx->stats.reduce_inliers = 0;
+  ctx->stats.reduce_launches = 0;
 
   size_t i = 0;
   while (i < n) {

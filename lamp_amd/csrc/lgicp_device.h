@@ -78,6 +78,7 @@ struct PairState {
   int failed;  // optimiser "exception" (fewer than 4 correspondences)
   int m;       // correspondences of the last outer iteration
   int pad;
+  double m_sum;  // correspondences summed over the outer iterations (statistics only)
 };
 
 struct SolveParams {

