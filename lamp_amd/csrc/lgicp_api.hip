@@ -22,7 +22,9 @@
 #include "host_math.h"
 #include "lgicp_device.h"
 
+#include <atomic>
 #include <limits>
+#include <thread>
 
 #include "lgicp_internal.h"
 #include "spatial_index.h"
@@ -32,12 +34,12 @@ namespace {
 inline int round_up(int n, int m) { return ((n + m - 1) / m) * m; }
 
 struct Arena {
-  lgicp_ctx* ctx;
+  BatchSlot* slot;
   size_t off = 0;
   template <typename T>
   T* take(size_t n) {
     off = (off + 255) & ~(size_t)255;
-    T* p = reinterpret_cast<T*>(ctx->arena.p + off);
+    T* p = reinterpret_cast<T*>(slot->arena.p + off);
     off += n * sizeof(T);
     return p;
   }
@@ -167,12 +169,16 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
     const float r0 = 1e-3f * (float)cfg->reserved[3];
     ctx->nn_r0sq = r0 * r0;
   }
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->flag_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipHostMalloc((void**)&ctx->h_done, sizeof(int) * 65536, hipHostMallocDefault) != hipSuccess) {
+  if (cfg->reserved[7] >= 1 && cfg->reserved[7] <= lgicp_ctx::MAX_SLOTS)
+    ctx->n_slots = cfg->reserved[7];
+  bool slots_ok = true;
+  for (int k = 0; k < ctx->n_slots; ++k) slots_ok = slots_ok && ctx->slot[k].create();
+  if (!slots_ok) {
+    for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
     delete ctx;
     return fail(nullptr, LGICP_E_HIP, "stream / pinned allocation failed");
   }
+  ctx->stream = ctx->slot[0].stream;
   *out = ctx;
   return LGICP_OK;
 }
@@ -180,25 +186,9 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
 void lgicp_destroy(lgicp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->cfg.device);
-  (void)hipStreamSynchronize(ctx->stream);
+  for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
   for (auto& kv : ctx->scans) kv.second.free_device();
   ctx->d_isegs.release();
-  ctx->d_counters.release();
-  ctx->arena.release();
-  ctx->d_clouds.release();
-  ctx->d_pairs.release();
-  ctx->d_state.release();
-  ctx->d_segs.release();
-  ctx->d_bmap_nn.release();
-  ctx->d_bmap_red.release();
-  ctx->d_bmap_nn_all.release();
-  ctx->d_bmap_red_all.release();
-  if (ctx->flag_stream) (void)hipStreamDestroy(ctx->flag_stream);
-  ctx->d_ints.release();
-  ctx->d_partials.release();
-  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-  if (ctx->h_done) (void)hipHostFree(ctx->h_done);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -329,9 +319,10 @@ void guess_from_pose(const hm::Pose& p, bool with_translation, float g[16]) {
 }
 
 // runs one device batch; results for bp.pairs[i] go to out[bp.pairs[i].cand]
-int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_result* out) {
+int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate* cand,
+              lgicp_result* out) {
   const lgicp_config& cfg = ctx->cfg;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = W->stream;
   const int n_pairs = (int)bp.pairs.size();
   const int n_clouds = (int)bp.clouds.size();
   if (n_pairs == 0) return LGICP_OK;
@@ -339,8 +330,8 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   // ---- device scratch ----------------------------------------------------------------------
   size_t pair_bytes = 0;
   for (auto& p : bp.pairs) pair_bytes += (size_t)bp.clouds[p.src_cloud].n * 24 + 512;
-  HIP_TRY(ctx, ctx->arena.reserve(bp.bytes + pair_bytes + 4096));
-  Arena ar{ctx};
+  HIP_TRY(ctx, W->arena.reserve(bp.bytes + pair_bytes + 4096));
+  Arena ar{W};
 
   std::vector<CloudDev> h_clouds((size_t)n_clouds);
   std::vector<SegmentDev> h_segs;
@@ -507,60 +498,60 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   const size_t off_ids = (size_t)2 * n_pairs + 4;
   const size_t off_done = (size_t)n_pairs;  // n_done, then one "active" flag per pair
 
-  HIP_TRY(ctx, ctx->d_clouds.reserve(n_clouds));
-  HIP_TRY(ctx, ctx->d_pairs.reserve(n_pairs));
-  HIP_TRY(ctx, ctx->d_state.reserve(n_pairs));
-  HIP_TRY(ctx, ctx->d_segs.reserve(std::max<size_t>(h_segs.size(), 1)));
-  HIP_TRY(ctx, ctx->d_bmap_nn.reserve(std::max(max_nn_blocks, h_bmap_nn.size())));
-  HIP_TRY(ctx, ctx->d_bmap_red.reserve(h_bmap_red.size()));
-  HIP_TRY(ctx, ctx->d_ints.reserve(h_ints.size()));
-  HIP_TRY(ctx, ctx->d_partials.reserve((size_t)n_pairs * RED_MAX_CHUNKS * NSTAT));
-  HIP_TRY(ctx, ctx->d_isegs.reserve(std::max<size_t>(h_isegs.size(), 1)));
-  HIP_TRY(ctx, ctx->d_counters.reserve(NN_COUNTER_SLOTS));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters.p, 0, sizeof(unsigned long long) * NN_COUNTER_SLOTS, st));
+  HIP_TRY(ctx, W->d_clouds.reserve(n_clouds));
+  HIP_TRY(ctx, W->d_pairs.reserve(n_pairs));
+  HIP_TRY(ctx, W->d_state.reserve(n_pairs));
+  HIP_TRY(ctx, W->d_segs.reserve(std::max<size_t>(h_segs.size(), 1)));
+  HIP_TRY(ctx, W->d_bmap_nn.reserve(std::max(max_nn_blocks, h_bmap_nn.size())));
+  HIP_TRY(ctx, W->d_bmap_red.reserve(h_bmap_red.size()));
+  HIP_TRY(ctx, W->d_ints.reserve(h_ints.size()));
+  HIP_TRY(ctx, W->d_partials.reserve((size_t)n_pairs * RED_MAX_CHUNKS * NSTAT));
+  HIP_TRY(ctx, W->d_isegs.reserve(std::max<size_t>(h_isegs.size(), 1)));
+  HIP_TRY(ctx, W->d_counters.reserve(NN_COUNTER_SLOTS));
+  HIP_TRY(ctx, hipMemsetAsync(W->d_counters.p, 0, sizeof(unsigned long long) * NN_COUNTER_SLOTS, st));
   if (!h_isegs.empty())
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_isegs.p, h_isegs.data(), sizeof(IndexSegDev) * h_isegs.size(),
+    HIP_TRY(ctx, hipMemcpyAsync(W->d_isegs.p, h_isegs.data(), sizeof(IndexSegDev) * h_isegs.size(),
                                 hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_clouds.p, h_clouds.data(), sizeof(CloudDev) * n_clouds,
+  HIP_TRY(ctx, hipMemcpyAsync(W->d_clouds.p, h_clouds.data(), sizeof(CloudDev) * n_clouds,
                               hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
+  HIP_TRY(ctx, hipMemcpyAsync(W->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
                               hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state.p, h_state.data(), sizeof(PairState) * n_pairs,
+  HIP_TRY(ctx, hipMemcpyAsync(W->d_state.p, h_state.data(), sizeof(PairState) * n_pairs,
                               hipMemcpyHostToDevice, st));
   if (!h_segs.empty())
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_segs.p, h_segs.data(), sizeof(SegmentDev) * h_segs.size(),
+    HIP_TRY(ctx, hipMemcpyAsync(W->d_segs.p, h_segs.data(), sizeof(SegmentDev) * h_segs.size(),
                                 hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size(),
+  HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_nn.p, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size(),
                               hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
+  HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_red.p, h_bmap_red.data(),
                               sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
   // the pass after the loop covers every pair again: its maps stay resident beside the live ones
   const int n_all_nn = (int)h_bmap_nn.size(), n_all_red = (int)h_bmap_red.size();
   const bool all_split = any_split;
-  HIP_TRY(ctx, ctx->d_bmap_nn_all.reserve(h_bmap_nn.size()));
-  HIP_TRY(ctx, ctx->d_bmap_red_all.reserve(h_bmap_red.size()));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn_all.p, h_bmap_nn.data(),
+  HIP_TRY(ctx, W->d_bmap_nn_all.reserve(h_bmap_nn.size()));
+  HIP_TRY(ctx, W->d_bmap_red_all.reserve(h_bmap_red.size()));
+  HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_nn_all.p, h_bmap_nn.data(),
                               sizeof(int4) * h_bmap_nn.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red_all.p, h_bmap_red.data(),
+  HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_red_all.p, h_bmap_red.data(),
                               sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ints.p, h_ints.data(), sizeof(int) * h_ints.size(),
+  HIP_TRY(ctx, hipMemcpyAsync(W->d_ints.p, h_ints.data(), sizeof(int) * h_ints.size(),
                               hipMemcpyHostToDevice, st));
   // the host vectors above must outlive the copies
   HIP_TRY(ctx, hipStreamSynchronize(st));
 
-  ctx->ev_used = 0;
-  hipEvent_t ev_begin = ctx->event(), ev_prep = ctx->event();
+  W->ev_used = 0;
+  hipEvent_t ev_begin = W->event(), ev_prep = W->event();
   HIP_TRY(ctx, hipEventRecord(ev_begin, st));
 
   // ---- clouds: accumulate, pad, covariances, normalisation constants --------------------------
-  HIP_TRY(ctx, launch_assemble(ctx->d_segs.p, (int)h_segs.size(), max_seg_n, st));
+  HIP_TRY(ctx, launch_assemble(W->d_segs.p, (int)h_segs.size(), max_seg_n, st));
   for (int c = 0; c < n_clouds; ++c)
     if (bp.clouds[c].accumulated)
       HIP_TRY(ctx, launch_pad_fill(const_cast<float4*>(h_clouds[c].xyz), h_clouds[c].n,
                                    h_clouds[c].n_pad, st));
-  HIP_TRY(ctx, launch_index_fill(ctx->d_isegs.p, (int)h_isegs.size(), max_iseg_n, st));
+  HIP_TRY(ctx, launch_index_fill(W->d_isegs.p, (int)h_isegs.size(), max_iseg_n, st));
   // no previous match to seed the first lookup with
-  HIP_TRY(ctx, launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, true, st));
+  HIP_TRY(ctx, launch_keys_fill(W->d_pairs.p, W->d_state.p, n_pairs, max_src_n, true, st));
   if (cfg.covariance_from_knn) {
     for (int c = 0; c < n_clouds; ++c)
       HIP_TRY(ctx, launch_cov_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
@@ -571,7 +562,7 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
       HIP_TRY(ctx, launch_cov_from_normals(h_clouds[c].nrm, h_clouds[c].n,
                                            const_cast<double*>(h_clouds[c].cov), st));
   }
-  HIP_TRY(ctx, launch_normalize_constants(ctx->d_clouds.p, ctx->d_ints.p + off_ids,
+  HIP_TRY(ctx, launch_normalize_constants(W->d_clouds.p, W->d_ints.p + off_ids,
                                           (int)scan1_ids.size(), st));
 
   // ---- FEATURES / TEASERPP initialisation (IcpLoopComputation.cc:517-531, 650-705, 949-1081) --
@@ -620,12 +611,12 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
       }
       if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
+    HIP_TRY(ctx, hipMemcpyAsync(W->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
                                 hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state.p, h_state.data(), sizeof(PairState) * n_pairs,
+    HIP_TRY(ctx, hipMemcpyAsync(W->d_state.p, h_state.data(), sizeof(PairState) * n_pairs,
                                 hipMemcpyHostToDevice, st));
   }
-  HIP_TRY(ctx, launch_guess_transform(ctx->d_clouds.p, ctx->d_pairs.p, n_pairs, max_src_n, st));
+  HIP_TRY(ctx, launch_guess_transform(W->d_clouds.p, W->d_pairs.p, n_pairs, max_src_n, st));
   HIP_TRY(ctx, hipEventRecord(ev_prep, st));
 
   // ---- GICP outer loop -----------------------------------------------------------------------
@@ -635,7 +626,7 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   sp.tf_epsilon = cfg.tf_epsilon;
   sp.max_iterations = cfg.iterations;
   sp.max_inner_iterations = cfg.optimizer_iterations;
-  int* d_done = ctx->d_ints.p + off_done;
+  int* d_done = W->d_ints.p + off_done;
   // One 1-NN pass over the pairs of the current block map.  Inside the GICP loop only matches
   // closer than the correspondence threshold are used (gicp.hpp:476), so the pruned search is
   // capped just above it; the pass after the loop is exact for every point.
@@ -643,19 +634,19 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   if (cfg.reserved[4] > 0)  // diagnostics only: a smaller cap drops correspondences
     nn_cap = 1e-6f * (float)cfg.reserved[4] * (float)cfg.reserved[4];
   auto nn_pass = [&](bool final_pass) -> hipError_t {
-    const int4* map = final_pass ? ctx->d_bmap_nn_all.p : ctx->d_bmap_nn.p;
+    const int4* map = final_pass ? W->d_bmap_nn_all.p : W->d_bmap_nn.p;
     const int n_map = final_pass ? n_all_nn : (int)h_bmap_nn.size();
     const bool split = final_pass ? all_split : any_split;
     if (!ctx->nn_exhaustive)
-      return launch_nn_pruned(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, map, n_map,
+      return launch_nn_pruned(W->d_clouds.p, W->d_pairs.p, W->d_state.p, map, n_map,
                               final_pass,
                               final_pass ? std::numeric_limits<float>::infinity() : nn_cap,
-                              ctx->nn_r0sq, cfg.reserved[6] != 1, ctx->d_counters.p, st);
+                              ctx->nn_r0sq, cfg.reserved[6] != 1, W->d_counters.p, st);
     if (split) {
-      hipError_t e = launch_keys_fill(ctx->d_pairs.p, ctx->d_state.p, n_pairs, max_src_n, final_pass, st);
+      hipError_t e = launch_keys_fill(W->d_pairs.p, W->d_state.p, n_pairs, max_src_n, final_pass, st);
       if (e != hipSuccess) return e;
     }
-    return launch_nn_search(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p, map, n_map,
+    return launch_nn_search(W->d_clouds.p, W->d_pairs.p, W->d_state.p, map, n_map,
                             final_pass, split, ctx->nn_variant, st);
   };
   std::vector<int> active;
@@ -664,9 +655,9 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   const int n_inactive0 = n_pairs - (int)active.size();
   if (n_inactive0) {
     build_maps(active);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, h_bmap_nn.data(),
+    HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_nn.p, h_bmap_nn.data(),
                                 sizeof(int4) * h_bmap_nn.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, h_bmap_red.data(),
+    HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_red.p, h_bmap_red.data(),
                                 sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
   }
@@ -679,26 +670,26 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
   // "done" flags of iteration i are looked at, so the device never waits for the round trip.
   // Pairs that have left the loop are skipped by the kernels themselves (PairState::active);
   // the block maps only follow, two iterations late, to keep the grids small.
-  hipEvent_t flag_ev[2] = {ctx->event(), ctx->event()};
-  int* h_flags2[2] = {ctx->h_done, ctx->h_done + 32768};
+  hipEvent_t flag_ev[2] = {W->event(), W->event()};
+  int* h_flags2[2] = {W->h_done, W->h_done + 32768};
   auto enqueue_iteration = [&](int slot) -> int {
-    hipEvent_t a = ctx->event(), b = ctx->event(), c = ctx->event(), d = ctx->event();
+    hipEvent_t a = W->event(), b = W->event(), c = W->event(), d = W->event();
     HIP_TRY(ctx, hipEventRecord(a, st));
     HIP_TRY(ctx, nn_pass(false));
     HIP_TRY(ctx, hipEventRecord(b, st));
-    HIP_TRY(ctx, launch_gicp_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
-                                    ctx->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
-                                    ctx->d_partials.p, st));
+    HIP_TRY(ctx, launch_gicp_reduce(W->d_clouds.p, W->d_pairs.p, W->d_state.p,
+                                    W->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
+                                    W->d_partials.p, st));
     HIP_TRY(ctx, hipEventRecord(c, st));
-    HIP_TRY(ctx, launch_gicp_solve(ctx->d_pairs.p, ctx->d_state.p, n_pairs, ctx->d_ints.p,
-                                   ctx->d_partials.p, sp, d_done, st));
+    HIP_TRY(ctx, launch_gicp_solve(W->d_pairs.p, W->d_state.p, n_pairs, W->d_ints.p,
+                                   W->d_partials.p, sp, d_done, st));
     HIP_TRY(ctx, hipEventRecord(d, st));
     // the flags travel on their own stream: the next iteration does not queue up behind the copy
     // (a copy that overlaps the next solve kernel can only see more pairs done, never fewer)
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->flag_stream, d, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(W->flag_stream, d, 0));
     HIP_TRY(ctx, hipMemcpyAsync(h_flags2[slot], d_done, sizeof(int) * ((size_t)n_pairs + 1),
-                                hipMemcpyDeviceToHost, ctx->flag_stream));
-    HIP_TRY(ctx, hipEventRecord(flag_ev[slot], ctx->flag_stream));
+                                hipMemcpyDeviceToHost, W->flag_stream));
+    HIP_TRY(ctx, hipEventRecord(flag_ev[slot], W->flag_stream));
     nn_ev.emplace_back(a, b);
     red_ev.emplace_back(b, c);
     sol_ev.emplace_back(c, d);
@@ -741,9 +732,9 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
           stage_k ^= 1;
           s_nn = h_bmap_nn;
           s_red = h_bmap_red;
-          HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_nn.p, s_nn.data(), sizeof(int4) * s_nn.size(),
+          HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_nn.p, s_nn.data(), sizeof(int4) * s_nn.size(),
                                       hipMemcpyHostToDevice, st));
-          HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bmap_red.p, s_red.data(), sizeof(int4) * s_red.size(),
+          HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_red.p, s_red.data(), sizeof(int4) * s_red.size(),
                                       hipMemcpyHostToDevice, st));
         }
       }
@@ -754,29 +745,29 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
       }
     }
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->flag_stream));
+  HIP_TRY(ctx, hipStreamSynchronize(W->flag_stream));
 
   // ---- final pass: fitness + correspondences + Ap ----------------------------------------------
-  hipEvent_t ev_post0 = ctx->event(), ev_post1 = ctx->event(), ev_post2 = ctx->event();
+  hipEvent_t ev_post0 = W->event(), ev_post1 = W->event(), ev_post2 = W->event();
   HIP_TRY(ctx, hipEventRecord(ev_post0, st));
   HIP_TRY(ctx, nn_pass(true));
   HIP_TRY(ctx, hipEventRecord(ev_post1, st));
-  HIP_TRY(ctx, launch_post_reduce(ctx->d_clouds.p, ctx->d_pairs.p, ctx->d_state.p,
-                                  ctx->d_bmap_red_all.p, n_all_red, ctx->d_partials.p,
+  HIP_TRY(ctx, launch_post_reduce(W->d_clouds.p, W->d_pairs.p, W->d_state.p,
+                                  W->d_bmap_red_all.p, n_all_red, W->d_partials.p,
                                   cfg.covariance_method == LGICP_COV_POINT2POINT &&
                                       !cfg.use_fixed_covariances,
                                   st));
   HIP_TRY(ctx, hipEventRecord(ev_post2, st));
   std::vector<double> h_post((size_t)n_pairs * RED_MAX_CHUNKS * NPOST);
-  HIP_TRY(ctx, hipMemcpyAsync(h_post.data(), ctx->d_partials.p, sizeof(double) * h_post.size(),
+  HIP_TRY(ctx, hipMemcpyAsync(h_post.data(), W->d_partials.p, sizeof(double) * h_post.size(),
                               hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(h_state.data(), ctx->d_state.p, sizeof(PairState) * n_pairs,
+  HIP_TRY(ctx, hipMemcpyAsync(h_state.data(), W->d_state.p, sizeof(PairState) * n_pairs,
                               hipMemcpyDeviceToHost, st));
   std::vector<unsigned long long> h_counters(NN_COUNTER_SLOTS, 0);
-  HIP_TRY(ctx, hipMemcpyAsync(h_counters.data(), ctx->d_counters.p,
+  HIP_TRY(ctx, hipMemcpyAsync(h_counters.data(), W->d_counters.p,
                               sizeof(unsigned long long) * NN_COUNTER_SLOTS, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
-  for (unsigned long long v : h_counters) ctx->stats.nn_executed_evals += (double)v;
+  for (unsigned long long v : h_counters) W->stats.nn_executed_evals += (double)v;
 
   // ---- timing ------------------------------------------------------------------------------
   auto sum_ms = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
@@ -788,7 +779,7 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
     return s;
   };
   float ms = 0;
-  lgicp_stats& S = ctx->stats;
+  lgicp_stats& S = W->stats;
   const double nn_loop_ms = sum_ms(nn_ev);
   (void)hipEventElapsedTime(&ms, ev_post0, ev_post1);
   const double nn_final_ms = ms;
@@ -890,45 +881,79 @@ int run_batch(lgicp_ctx* ctx, BatchPlan& bp, const lgicp_candidate* cand, lgicp_
 
 }  // namespace
 
+namespace {
+
+void merge_stats(lgicp_stats& into, const lgicp_stats& d) {
+  into.pairs_ok += d.pairs_ok;
+  into.outer_iterations += d.outer_iterations;
+  into.nn_launches += d.nn_launches;
+  into.nn_distance_evals += d.nn_distance_evals;
+  into.nn_ms += d.nn_ms, into.reduce_ms += d.reduce_ms, into.solve_ms += d.solve_ms;
+  into.cov_ms += d.cov_ms, into.post_ms += d.post_ms;
+  into.nn_executed_evals += d.nn_executed_evals;
+  into.reduce_points += d.reduce_points, into.reduce_inliers += d.reduce_inliers;
+  into.reduce_launches += d.reduce_launches;
+  if (d.last_nn_evals_per_launch > 0) {
+    into.last_nn_kernel_ms = d.last_nn_kernel_ms;
+    into.last_nn_evals_per_launch = d.last_nn_evals_per_launch;
+  }
+}
+
+void reset_submit_stats(lgicp_stats& s) {
+  s.nn_ms = s.reduce_ms = s.solve_ms = s.cov_ms = s.post_ms = s.total_ms = 0;
+  s.nn_executed_evals = s.reduce_points = s.reduce_inliers = 0;
+  s.reduce_launches = 0;
+}
+
+}  // namespace
+
 extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n,
                             lgicp_result* out) {
   if (!ctx) return LGICP_E_INVALID;
   if (n && (!cand || !out)) return fail(ctx, LGICP_E_INVALID, "null argument");
   const lgicp_config& cfg = ctx->cfg;
   HIP_TRY(ctx, hipSetDevice(cfg.device));
-  ctx->stats.nn_ms = ctx->stats.reduce_ms = ctx->stats.solve_ms = ctx->stats.cov_ms =
-      ctx->stats.post_ms = ctx->stats.total_ms = 0;
-  ctx->stats.nn_executed_evals = 0;
-  ctx->stats.reduce_points = ctx->stats.reduce_inliers = 0;
-  ctx->stats.reduce_launches = 0;
+  reset_submit_stats(ctx->stats);
 
+  // PerformAlignment's availability checks (IcpLoopComputation.cc:438-465)
+  size_t n_valid = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const lgicp_candidate& c = cand[i];
+    lgicp_result& r = out[i];
+    std::memset(&r, 0, sizeof(r));
+    r.key_from = c.key_from;
+    r.key_to = c.key_to;
+    r.status = LGICP_PAIR_OK;
+    ctx->stats.pairs_submitted++;
+    if (!ctx->scans.count(c.key_from) || !ctx->scans.count(c.key_to))
+      r.status = LGICP_PAIR_MISSING_SCAN;
+    else if (!ctx->poses.count(c.key_from) || !ctx->poses.count(c.key_to))
+      r.status = LGICP_PAIR_MISSING_POSE;
+    else if (ctx->scans.at(c.key_from).n == 0 || ctx->scans.at(c.key_to).n == 0)
+      r.status = LGICP_PAIR_EMPTY_CLOUD;
+    else
+      ++n_valid;
+  }
+
+  // Several parts in flight at once when the submit is large enough (the feature-based
+  // initialisations run their host stage on the context's own stream and stay serial).
+  int ways = ctx->n_slots;
+  if (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP) ways = 1;
+  while (ways > 1 && n_valid < (size_t)32 * ways) --ways;
+  const size_t max_pairs = std::min<size_t>(32767, (n_valid + ways - 1) / std::max(ways, 1));
+  const size_t max_bytes = cfg.workspace_bytes / ways;
+
+  std::vector<BatchPlan> plans;
   size_t i = 0;
   while (i < n) {
     BatchPlan bp;
     size_t pair_bytes = 0;
     for (; i < n; ++i) {
       const lgicp_candidate& c = cand[i];
-      lgicp_result& r = out[i];
-      std::memset(&r, 0, sizeof(r));
-      r.key_from = c.key_from;
-      r.key_to = c.key_to;
-      ctx->stats.pairs_submitted++;
-      // PerformAlignment's availability checks (IcpLoopComputation.cc:438-465)
-      if (!ctx->scans.count(c.key_from) || !ctx->scans.count(c.key_to)) {
-        r.status = LGICP_PAIR_MISSING_SCAN;
-        continue;
-      }
-      if (!ctx->poses.count(c.key_from) || !ctx->poses.count(c.key_to)) {
-        r.status = LGICP_PAIR_MISSING_POSE;
-        continue;
-      }
-      if (ctx->scans.at(c.key_from).n == 0 || ctx->scans.at(c.key_to).n == 0) {
-        r.status = LGICP_PAIR_EMPTY_CLOUD;
-        continue;
-      }
+      if (out[i].status != LGICP_PAIR_OK) continue;
       const size_t est = (size_t)ctx->scans.at(c.key_from).n * 24 * (cfg.accumulate_source ? 5 : 1);
       if (!bp.pairs.empty() &&
-          (bp.bytes + pair_bytes + est > cfg.workspace_bytes || bp.pairs.size() >= 32767))
+          (bp.bytes + pair_bytes + est > max_bytes || bp.pairs.size() >= max_pairs))
         break;
       PairPlan pp;
       pp.cand = i;
@@ -957,10 +982,43 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
       pair_bytes += (size_t)bp.clouds[pp.src_cloud].n * 24 + 512;
       bp.pairs.push_back(pp);
     }
-    const int rc = run_batch(ctx, bp, cand, out);
-    if (rc != LGICP_OK) return rc;
+    if (!bp.pairs.empty()) plans.push_back(std::move(bp));
   }
-  return LGICP_OK;
+
+  std::atomic<size_t> next{0};
+  std::atomic<int> rc_all{LGICP_OK};
+  std::mutex stats_mu;
+  double slot_total_ms[lgicp_ctx::MAX_SLOTS] = {0, 0, 0, 0};
+  auto worker = [&](int si) {
+    if (hipSetDevice(cfg.device) != hipSuccess) {
+      rc_all = fail(ctx, LGICP_E_HIP, "hipSetDevice failed");
+      return;
+    }
+    BatchSlot* W = &ctx->slot[si];
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= plans.size() || rc_all != LGICP_OK) break;
+      std::memset(&W->stats, 0, sizeof(W->stats));
+      const int rc = run_batch(ctx, W, plans[k], cand, out);
+      std::lock_guard<std::mutex> lock(stats_mu);
+      merge_stats(ctx->stats, W->stats);
+      slot_total_ms[si] += W->stats.total_ms;
+      if (rc != LGICP_OK) {
+        rc_all = rc;
+        break;
+      }
+    }
+  };
+  {
+    const int n_workers = (int)std::min<size_t>((size_t)ways, plans.size());
+    std::vector<std::thread> others;
+    for (int k = 1; k < n_workers; ++k) others.emplace_back(worker, k);
+    worker(0);
+    for (auto& t : others) t.join();
+  }
+  // device span of the submit: the slots overlap
+  ctx->stats.total_ms = *std::max_element(slot_total_ms, slot_total_ms + lgicp_ctx::MAX_SLOTS);
+  return rc_all;
 }
 
 // One alignment with an explicit guess: the two clouds become temporary keyframes (keys far
@@ -996,9 +1054,12 @@ extern "C" int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* sr
     std::memset(&c, 0, sizeof(c));
     lgicp_result r;
     std::memset(&r, 0, sizeof(r));
-    ctx->stats.nn_ms = ctx->stats.reduce_ms = ctx->stats.solve_ms = ctx->stats.cov_ms =
-        ctx->stats.post_ms = ctx->stats.total_ms = 0;
-    rc = hipSetDevice(ctx->cfg.device) == hipSuccess ? run_batch(ctx, bp, &c, &r) : LGICP_E_HIP;
+    reset_submit_stats(ctx->stats);
+    std::memset(&ctx->slot[0].stats, 0, sizeof(lgicp_stats));
+    rc = hipSetDevice(ctx->cfg.device) == hipSuccess ? run_batch(ctx, &ctx->slot[0], bp, &c, &r)
+                                                     : LGICP_E_HIP;
+    merge_stats(ctx->stats, ctx->slot[0].stats);
+    ctx->stats.total_ms = ctx->slot[0].stats.total_ms;
     if (rc == LGICP_OK) {
       std::memcpy(final_T, r.T_icp, sizeof(r.T_icp));
       if (converged) *converged = r.converged;

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -65,33 +66,28 @@ struct DevBuf {  // grow-only device array
 }  // namespace lgicp_detail
 using namespace lgicp_detail;
 
-struct lgicp_ctx {
-  lgicp_config cfg;
+// Everything one in-flight batch needs on the device and for talking to it.  A context owns
+// several of these so that parts of a submit can be in flight at once: while one half sits in
+// a latency-bound stretch (the 6x6 solves, the last stragglers of the outer loop, host
+// bookkeeping) the other half's bulk kernels keep the GPU busy.
+struct BatchSlot {
   hipStream_t stream = nullptr;
-  std::unordered_map<uint64_t, Keyframe> scans;
-  std::unordered_map<uint64_t, hm::Pose> poses;
-  std::string err;
-  lgicp_stats stats;
-  int nn_variant = 4;
-
-  DevBuf<char> arena;  // per-batch scratch (bump allocated)
-  size_t arena_off = 0;
+  hipStream_t flag_stream = nullptr;  // carries the "done" flags back to the host
+  DevBuf<char> arena;                 // per-batch scratch (bump allocated)
   DevBuf<CloudDev> d_clouds;
   DevBuf<PairDev> d_pairs;
   DevBuf<PairState> d_state;
   DevBuf<SegmentDev> d_segs;
   DevBuf<int4> d_bmap_nn, d_bmap_red;          // block maps of the pairs still in the loop
   DevBuf<int4> d_bmap_nn_all, d_bmap_red_all;  // block maps of every pair of the batch
-  hipStream_t flag_stream = nullptr;            // carries the "done" flags back to the host
-  DevBuf<int> d_ints;  // n_chunks[n_pairs] | scan1 ids | n_done
+  DevBuf<int> d_ints;  // n_chunks[n_pairs] | n_done, done flags | scan1 ids
   DevBuf<double> d_partials;
   DevBuf<IndexSegDev> d_isegs;
   DevBuf<unsigned long long> d_counters;
-  bool nn_exhaustive = false;  // reserved[2] = 1: the dense 1-NN kernel instead of the pruned one
-  float nn_r0sq = 1.0f / 64.0f;  // squared radius of the pruned search's first round
-  int* h_done = nullptr;  // pinned
+  int* h_done = nullptr;  // pinned, 2 x 32768
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
+  lgicp_stats stats;  // what the batch in this slot adds to the context's statistics
 
   hipEvent_t event() {
     if (ev_used == ev_pool.size()) {
@@ -101,6 +97,41 @@ struct lgicp_ctx {
     }
     return ev_pool[ev_used++];
   }
+  bool create() {
+    return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+           hipStreamCreateWithFlags(&flag_stream, hipStreamNonBlocking) == hipSuccess &&
+           hipHostMalloc((void**)&h_done, sizeof(int) * 65536, hipHostMallocDefault) == hipSuccess;
+  }
+  void destroy() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (flag_stream) (void)hipStreamSynchronize(flag_stream);
+    arena.release(), d_clouds.release(), d_pairs.release(), d_state.release(), d_segs.release();
+    d_bmap_nn.release(), d_bmap_red.release(), d_bmap_nn_all.release(), d_bmap_red_all.release();
+    d_ints.release(), d_partials.release(), d_isegs.release(), d_counters.release();
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+    ev_pool.clear();
+    if (h_done) (void)hipHostFree(h_done);
+    if (flag_stream) (void)hipStreamDestroy(flag_stream);
+    if (stream) (void)hipStreamDestroy(stream);
+    h_done = nullptr, stream = flag_stream = nullptr;
+  }
+};
+
+struct lgicp_ctx {
+  lgicp_config cfg;
+  std::unordered_map<uint64_t, Keyframe> scans;
+  std::unordered_map<uint64_t, hm::Pose> poses;
+  std::string err;
+  std::mutex err_mu;
+  lgicp_stats stats;
+  int nn_variant = 4;
+  bool nn_exhaustive = false;  // reserved[2] = 1: the dense 1-NN kernel instead of the pruned one
+  float nn_r0sq = 1.0f / 64.0f;  // squared radius of the pruned search's first round
+  static constexpr int MAX_SLOTS = 4;
+  BatchSlot slot[MAX_SLOTS];
+  int n_slots = 2;  // halves (or quarters) of a submit in flight at once; reserved[7] overrides
+  hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
+  DevBuf<IndexSegDev> d_isegs;   // for keyframe registration
 };
 
 namespace lgicp_detail {
@@ -128,9 +159,10 @@ inline int fail(lgicp_ctx* ctx, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (ctx)
+  if (ctx) {
+    std::lock_guard<std::mutex> lock(ctx->err_mu);
     ctx->err = buf;
-  else
+  } else
     g_create_error = buf;
   return code;
 }

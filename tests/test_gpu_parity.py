@@ -482,3 +482,69 @@ def test_submit_teaser_init_matches_oracle():
         assert ang < 1e-4 and te < 1e-4
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------ pruned vs exhaustive 1-NN
+def _nn_both(src, tgt, T=None):
+    from lamp_amd import capi
+    T = np.eye(4, dtype=np.float32) if T is None else T
+    res = [0] * 8
+    out = []
+    for exhaustive in (0, 1):
+        res[2] = exhaustive
+        c = capi.Context(reserved=(capi.C.c_int * 8)(*res))
+        try:
+            out.append(c.nn_search(T, src, tgt))
+        finally:
+            c.close()
+    return out
+
+
+def test_pruned_nn_equals_exhaustive_at_full_size():
+    """The box-culled search and the exhaustive sweep are two independent kernels; at the
+    benchmark's keyframe size they must return the same (index, distance) for every query,
+    including duplicated targets (ties -> lowest index), far queries and clustered data."""
+    rng = np.random.default_rng(7)
+    room, _ = F.random_room_scan(16384, 3)
+    src, _ = F.random_room_scan(16384, 4)
+    tgt = room.copy()
+    tgt[5000:5200] = tgt[100:300]                       # exact duplicates
+    src[:50] += 40.0                                    # far away from everything
+    src[50:60] = tgt[5000:5010]                         # zero-distance ties
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = (0.05, -0.02, 0.01)
+    (i_p, d_p), (i_e, d_e) = _nn_both(src, tgt, T)
+    assert np.array_equal(i_p, i_e)
+    assert np.array_equal(d_p.view(np.uint32), d_e.view(np.uint32))
+    # ragged sizes and a target smaller than one tile
+    for n_s, n_t in [(1, 1), (63, 5), (65, 31), (1000, 33), (4097, 2049)]:
+        s = rng.normal(size=(n_s, 3)).astype(np.float32)
+        t = rng.normal(size=(n_t, 3)).astype(np.float32)
+        (i_p, d_p), (i_e, d_e) = _nn_both(s, t)
+        ref_i, ref_d = O.nn_brute(s, t)
+        assert np.array_equal(i_p, ref_i) and np.array_equal(i_e, ref_i), (n_s, n_t)
+        assert np.array_equal(d_p.view(np.uint32), ref_d.view(np.uint32))
+
+
+def test_submit_exhaustive_and_pruned_agree():
+    """Whole batch path with either lookup kernel: identical transforms, fitness, information."""
+    from lamp_amd import capi
+    outs = []
+    for exhaustive in (0, 1):
+        res = [0] * 8
+        res[2] = exhaustive
+        c = capi.Context(init_method=capi.INIT_IDENTITY, reserved=(capi.C.c_int * 8)(*res))
+        try:
+            for i in range(3):
+                src, sn, tgt, tn, _ = F.make_pair(5000 + 700 * i, 80 + i, rot_deg=2.5, trans=0.25)
+                _register(c, 100 + 10 * i, tgt, tn)
+                _register(c, 900 + 10 * i, src, sn)
+            outs.append([capi.result_to_dict(r) for r in
+                         c.submit([(900 + 10 * i, 100 + 10 * i) for i in range(3)])])
+        finally:
+            c.close()
+    for a, b in zip(*outs):
+        assert a["status"] == b["status"] == 0 and a["iterations"] == b["iterations"]
+        assert np.array_equal(a["T_icp"], b["T_icp"])
+        assert a["fitness"] == b["fitness"]
+        assert np.allclose(a["information"], b["information"], rtol=1e-12)

@@ -13,6 +13,7 @@ def main():
     res[2] = kw.pop("exhaustive", 0)
     res[3] = kw.pop("r0mm", 0)
     res[4] = kw.pop("capmm", 0)
+    res[7] = kw.pop("slots", 0)
     iters = kw.pop("iters", 200)
     n_pairs = kw.pop("pairs", 256)
     wl = workload.Workload("C2", pairs=n_pairs)
