@@ -89,6 +89,10 @@ __global__ void assemble_kernel(const SegmentDev* __restrict__ segs) {
     p.w = 1.0f;
     s.dst_xyz[i] = p;
     s.dst_nrm[i] = s.src_nrm[i];
+    if (s.src_cov) {  // normals are copied unrotated, so the covariances built from them are too
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s.dst_cov[6 * (size_t)i + k] = s.src_cov[6 * (size_t)i + k];
+    }
   }
 }
 

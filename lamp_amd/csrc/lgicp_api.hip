@@ -99,6 +99,28 @@ int build_keyframe_index(lgicp_ctx* ctx, Keyframe* kf, const float* xyz, size_t 
   return LGICP_OK;
 }
 
+// covariances from the normals and NormalizePCloud constants of a registered keyframe
+int build_keyframe_derived(lgicp_ctx* ctx, Keyframe* kf) {
+  const int n = kf->n;
+  if (n == 0) return LGICP_OK;
+  HIP_TRY(ctx, hipMalloc((void**)&kf->d_cov, sizeof(double) * 6 * (size_t)n));
+  HIP_TRY(ctx, launch_cov_from_normals(kf->d_nrm, n, kf->d_cov, ctx->stream));
+  CloudDev c;
+  std::memset(&c, 0, sizeof(c));
+  c.xyz = kf->d_xyz, c.n = n, c.n_pad = kf->n_pad;
+  const int id = 0;
+  HIP_TRY(ctx, ctx->d_reg_cloud.reserve(1));
+  HIP_TRY(ctx, ctx->d_reg_ids.reserve(1));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_reg_cloud.p, &c, sizeof(c), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_reg_ids.p, &id, sizeof(id), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, launch_normalize_constants(ctx->d_reg_cloud.p, ctx->d_reg_ids.p, 1, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(&c, ctx->d_reg_cloud.p, sizeof(c), hipMemcpyDeviceToHost));
+  std::memcpy(kf->centroid, c.centroid, sizeof(kf->centroid));
+  kf->factor = c.factor;
+  return LGICP_OK;
+}
+
 }  // namespace lgicp_detail
 
 extern "C" {
@@ -189,6 +211,8 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
   for (auto& kv : ctx->scans) kv.second.free_device();
   ctx->d_isegs.release();
+  ctx->d_reg_cloud.release();
+  ctx->d_reg_ids.release();
   delete ctx;
 }
 
@@ -222,7 +246,8 @@ int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const flo
                          hipMemcpyHostToDevice));
   if (n)
     HIP_TRY(ctx, hipMemcpy(kf.d_nrm, hn.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
-  const int rc = build_keyframe_index(ctx, &kf, xyz, sf);
+  int rc = build_keyframe_index(ctx, &kf, xyz, sf);
+  if (rc == LGICP_OK) rc = build_keyframe_derived(ctx, &kf);
   if (rc != LGICP_OK) {
     kf.free_device();
     return rc;
@@ -298,7 +323,7 @@ int plan_cloud(lgicp_ctx* ctx, BatchPlan& bp, uint64_t key, bool accumulate) {
   cp.n = ctx->scans.at(key).n;
   for (auto& s : cp.segs) cp.n += ctx->scans.at(s.first).n;
   cp.n_pad = std::max(NN_TILE, round_up(cp.n, NN_TILE));
-  bp.bytes += (size_t)cp.n * 48 + 256;                              // covariances
+  if (acc || ctx->cfg.covariance_from_knn) bp.bytes += (size_t)cp.n * 48 + 256;  // covariances
   if (acc) {
     bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 16 + 512;  // xyz + normals
     // spatial index: tile-ordered points, boxes, visiting order
@@ -344,11 +369,14 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     std::memset(&cd, 0, sizeof(cd));
     cd.n = cp.n;
     cd.n_pad = cp.n_pad;
-    cd.cov = ar.take<double>((size_t)cp.n * 6);
+    const bool own_cov = cp.accumulated || cfg.covariance_from_knn;
+    cd.cov = own_cov ? ar.take<double>((size_t)cp.n * 6) : kf.d_cov;
     max_cloud_n = std::max(max_cloud_n, cp.n);
     if (!cp.accumulated) {
       cd.xyz = kf.d_xyz;
       cd.nrm = kf.d_nrm;
+      std::memcpy(cd.centroid, kf.centroid, sizeof(cd.centroid));
+      cd.factor = kf.factor;
       cd.sxyz = kf.d_sxyz, cd.tmin = kf.d_tmin, cd.tmax = kf.d_tmax, cd.qorder = kf.d_qorder;
       cd.n_tiles = kf.n_tiles, cd.n_q = kf.n_q;
     } else {
@@ -384,10 +412,13 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
       int off = 0;
       SegmentDev s;
       std::memset(&s, 0, sizeof(s));
+      double* const acc_cov = cfg.covariance_from_knn ? nullptr : const_cast<double*>(cd.cov);
       s.src_xyz = kf.d_xyz;
       s.src_nrm = kf.d_nrm;
       s.dst_xyz = xyz;
       s.dst_nrm = nrm;
+      s.src_cov = acc_cov ? kf.d_cov : nullptr;
+      s.dst_cov = acc_cov;
       s.n = kf.n;
       s.identity = 1;
       h_segs.push_back(s);
@@ -400,6 +431,8 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
         s.src_nrm = nk.d_nrm;
         s.dst_xyz = xyz + off;
         s.dst_nrm = nrm + off;
+        s.src_cov = acc_cov ? nk.d_cov : nullptr;
+        s.dst_cov = acc_cov ? acc_cov + 6 * (size_t)off : nullptr;
         s.n = nk.n;
         s.identity = 0;
         for (int a = 0; a < 3; ++a) {
@@ -491,11 +524,6 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     evals_per_pass += (double)pd.n_src * (double)pd.n_tgt;
   }
   build_maps(all_pairs);
-  std::vector<int> scan1_ids;
-  for (int c = 0; c < n_clouds; ++c)
-    if (bp.clouds[c].need_norm_constants) scan1_ids.push_back(c);
-  for (size_t i = 0; i < scan1_ids.size(); ++i) h_ints.push_back(scan1_ids[i]);
-  const size_t off_ids = (size_t)2 * n_pairs + 4;
   const size_t off_done = (size_t)n_pairs;  // n_done, then one "active" flag per pair
 
   HIP_TRY(ctx, W->d_clouds.reserve(n_clouds));
@@ -557,13 +585,9 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
       HIP_TRY(ctx, launch_cov_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
                                   cfg.k_correspondences, cfg.gicp_epsilon,
                                   const_cast<double*>(h_clouds[c].cov), st));
-  } else {
-    for (int c = 0; c < n_clouds; ++c)
-      HIP_TRY(ctx, launch_cov_from_normals(h_clouds[c].nrm, h_clouds[c].n,
-                                           const_cast<double*>(h_clouds[c].cov), st));
   }
-  HIP_TRY(ctx, launch_normalize_constants(W->d_clouds.p, W->d_ints.p + off_ids,
-                                          (int)scan1_ids.size(), st));
+  // covariances from normals and the NormalizePCloud constants were derived when the keyframes
+  // were registered; accumulated clouds received their members' covariances in launch_assemble
 
   // ---- FEATURES / TEASERPP initialisation (IcpLoopComputation.cc:517-531, 650-705, 949-1081) --
   // Harris keypoints and FPFH descriptors once per distinct cloud of the batch, SAC-IA or

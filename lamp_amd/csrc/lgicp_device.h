@@ -99,6 +99,8 @@ struct SegmentDev {  // one keyframe appended to an accumulated cloud
   const float4* src_nrm;
   float4* dst_xyz;
   float4* dst_nrm;
+  const double* src_cov;  // optional: the keyframe's covariances-from-normals, copied along
+  double* dst_cov;
   double T[12];  // row-major 3x4, applied in double then cast (transformPointCloud<double>)
   int n;
   int identity;  // 1: plain copy (the key's own scan)

@@ -33,12 +33,18 @@ struct Keyframe {
   float4* d_tmin = nullptr;
   float4* d_tmax = nullptr;
   int* d_qorder = nullptr;
+  // derived once at registration: covariances from the normals (gicp_utils.h:28-62) and the
+  // NormalizePCloud constants (PointCloudUtils.cc:39-59); both depend on the keyframe alone
+  double* d_cov = nullptr;  // n x 6
+  float centroid[3] = {0.f, 0.f, 0.f};
+  float factor = 0.f;
   void free_device() {
     for (void* p : {(void*)d_xyz, (void*)d_nrm, (void*)d_order, (void*)d_sxyz, (void*)d_tmin,
-                    (void*)d_tmax, (void*)d_qorder})
+                    (void*)d_tmax, (void*)d_qorder, (void*)d_cov})
       if (p) (void)hipFree(p);
     d_xyz = d_nrm = d_sxyz = d_tmin = d_tmax = nullptr;
     d_order = d_qorder = nullptr;
+    d_cov = nullptr;
   }
 };
 
@@ -132,6 +138,8 @@ struct lgicp_ctx {
   int n_slots = 2;  // halves (or quarters) of a submit in flight at once; reserved[7] overrides
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
   DevBuf<IndexSegDev> d_isegs;   // for keyframe registration
+  DevBuf<CloudDev> d_reg_cloud;
+  DevBuf<int> d_reg_ids;
 };
 
 namespace lgicp_detail {
@@ -145,6 +153,7 @@ struct CloudFeatures {
 };
 // builds the spatial index of a device-resident cloud treated as one segment
 int build_keyframe_index(lgicp_ctx* ctx, Keyframe* kf, const float* xyz, size_t stride_floats);
+int build_keyframe_derived(lgicp_ctx* ctx, Keyframe* kf);
 int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
                            CloudFeatures* out);
 int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
