@@ -526,60 +526,82 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   build_maps(all_pairs);
   const size_t off_done = (size_t)n_pairs;  // n_done, then one "active" flag per pair
 
-  HIP_TRY(ctx, W->d_clouds.reserve(n_clouds));
-  HIP_TRY(ctx, W->d_pairs.reserve(n_pairs));
-  HIP_TRY(ctx, W->d_state.reserve(n_pairs));
-  HIP_TRY(ctx, W->d_segs.reserve(std::max<size_t>(h_segs.size(), 1)));
-  HIP_TRY(ctx, W->d_bmap_nn.reserve(std::max(max_nn_blocks, h_bmap_nn.size())));
-  HIP_TRY(ctx, W->d_bmap_red.reserve(h_bmap_red.size()));
-  HIP_TRY(ctx, W->d_ints.reserve(h_ints.size()));
-  HIP_TRY(ctx, W->d_partials.reserve((size_t)n_pairs * RED_MAX_CHUNKS * NSTAT));
-  HIP_TRY(ctx, W->d_isegs.reserve(std::max<size_t>(h_isegs.size(), 1)));
-  HIP_TRY(ctx, W->d_counters.reserve(NN_COUNTER_SLOTS));
-  HIP_TRY(ctx, hipMemsetAsync(W->d_counters.p, 0, sizeof(unsigned long long) * NN_COUNTER_SLOTS, st));
-  if (!h_isegs.empty())
-    HIP_TRY(ctx, hipMemcpyAsync(W->d_isegs.p, h_isegs.data(), sizeof(IndexSegDev) * h_isegs.size(),
-                                hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->d_clouds.p, h_clouds.data(), sizeof(CloudDev) * n_clouds,
-                              hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
-                              hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->d_state.p, h_state.data(), sizeof(PairState) * n_pairs,
-                              hipMemcpyHostToDevice, st));
-  if (!h_segs.empty())
-    HIP_TRY(ctx, hipMemcpyAsync(W->d_segs.p, h_segs.data(), sizeof(SegmentDev) * h_segs.size(),
-                                hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_nn.p, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size(),
-                              hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_red.p, h_bmap_red.data(),
-                              sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
-  // the pass after the loop covers every pair again: its maps stay resident beside the live ones
+  // ---- one upload -----------------------------------------------------------------------------
+  // Every host-built table goes through one pinned staging buffer and one copy; the live 1-NN
+  // block map sits last because later, smaller maps are written over it.
   const int n_all_nn = (int)h_bmap_nn.size(), n_all_red = (int)h_bmap_red.size();
   const bool all_split = any_split;
-  HIP_TRY(ctx, W->d_bmap_nn_all.reserve(h_bmap_nn.size()));
-  HIP_TRY(ctx, W->d_bmap_red_all.reserve(h_bmap_red.size()));
-  HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_nn_all.p, h_bmap_nn.data(),
-                              sizeof(int4) * h_bmap_nn.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_red_all.p, h_bmap_red.data(),
-                              sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->d_ints.p, h_ints.data(), sizeof(int) * h_ints.size(),
-                              hipMemcpyHostToDevice, st));
-  // the host vectors above must outlive the copies
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  size_t par_bytes = 0;
+  auto region = [&](size_t bytes) {
+    const size_t off = par_bytes;
+    par_bytes = (par_bytes + bytes + 255) & ~(size_t)255;
+    return off;
+  };
+  const size_t o_clouds = region(sizeof(CloudDev) * n_clouds);
+  const size_t o_pairs = region(sizeof(PairDev) * n_pairs);
+  const size_t o_state = region(sizeof(PairState) * n_pairs);
+  const size_t o_segs = region(sizeof(SegmentDev) * h_segs.size());
+  const size_t o_isegs = region(sizeof(IndexSegDev) * h_isegs.size());
+  const size_t o_ints = region(sizeof(int) * h_ints.size());
+  const size_t o_nn_all = region(sizeof(int4) * h_bmap_nn.size());
+  const size_t o_red_all = region(sizeof(int4) * h_bmap_red.size());
+  const size_t o_red = region(sizeof(int4) * h_bmap_red.size());
+  const size_t o_nn = region(sizeof(int4) * h_bmap_nn.size());
+  const size_t used_bytes = par_bytes;
+  par_bytes = o_nn + sizeof(int4) * std::max(max_nn_blocks, h_bmap_nn.size());
+  HIP_TRY(ctx, W->d_params.reserve(par_bytes));
+  if (W->h_params_cap < used_bytes) {
+    if (W->h_params) (void)hipHostFree(W->h_params);
+    W->h_params = nullptr;
+    W->h_params_cap = 0;
+    const size_t want = used_bytes + used_bytes / 4 + 4096;
+    HIP_TRY(ctx, hipHostMalloc((void**)&W->h_params, want, hipHostMallocDefault));
+    W->h_params_cap = want;
+  }
+  auto stage = [&](size_t off, const void* src, size_t bytes) {
+    if (bytes) std::memcpy(W->h_params + off, src, bytes);
+  };
+  stage(o_clouds, h_clouds.data(), sizeof(CloudDev) * n_clouds);
+  stage(o_pairs, h_pairs.data(), sizeof(PairDev) * n_pairs);
+  stage(o_state, h_state.data(), sizeof(PairState) * n_pairs);
+  stage(o_segs, h_segs.data(), sizeof(SegmentDev) * h_segs.size());
+  stage(o_isegs, h_isegs.data(), sizeof(IndexSegDev) * h_isegs.size());
+  stage(o_ints, h_ints.data(), sizeof(int) * h_ints.size());
+  stage(o_nn_all, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size());
+  stage(o_red_all, h_bmap_red.data(), sizeof(int4) * h_bmap_red.size());
+  stage(o_red, h_bmap_red.data(), sizeof(int4) * h_bmap_red.size());
+  stage(o_nn, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size());
+  char* const dpar = W->d_params.p;
+  CloudDev* const d_clouds = reinterpret_cast<CloudDev*>(dpar + o_clouds);
+  PairDev* const d_pairs = reinterpret_cast<PairDev*>(dpar + o_pairs);
+  PairState* const d_state = reinterpret_cast<PairState*>(dpar + o_state);
+  SegmentDev* const d_segs = reinterpret_cast<SegmentDev*>(dpar + o_segs);
+  IndexSegDev* const d_isegs = reinterpret_cast<IndexSegDev*>(dpar + o_isegs);
+  int* const d_ints = reinterpret_cast<int*>(dpar + o_ints);
+  int4* const d_bmap_nn_all = reinterpret_cast<int4*>(dpar + o_nn_all);
+  int4* const d_bmap_red_all = reinterpret_cast<int4*>(dpar + o_red_all);
+  int4* const d_bmap_red = reinterpret_cast<int4*>(dpar + o_red);
+  int4* const d_bmap_nn = reinterpret_cast<int4*>(dpar + o_nn);
+  HIP_TRY(ctx, W->d_partials.reserve((size_t)n_pairs * RED_MAX_CHUNKS * NSTAT));
+  HIP_TRY(ctx, W->d_counters.reserve(NN_COUNTER_SLOTS));
+  HIP_TRY(ctx, hipMemsetAsync(W->d_counters.p, 0, sizeof(unsigned long long) * NN_COUNTER_SLOTS, st));
+  // the staging buffer is rewritten only by the next batch of this slot, which starts after this
+  // batch's last synchronisation
+  HIP_TRY(ctx, hipMemcpyAsync(dpar, W->h_params, used_bytes, hipMemcpyHostToDevice, st));
 
   W->ev_used = 0;
   hipEvent_t ev_begin = W->event(), ev_prep = W->event();
   HIP_TRY(ctx, hipEventRecord(ev_begin, st));
 
   // ---- clouds: accumulate, pad, covariances, normalisation constants --------------------------
-  HIP_TRY(ctx, launch_assemble(W->d_segs.p, (int)h_segs.size(), max_seg_n, st));
+  HIP_TRY(ctx, launch_assemble(d_segs, (int)h_segs.size(), max_seg_n, st));
   for (int c = 0; c < n_clouds; ++c)
     if (bp.clouds[c].accumulated)
       HIP_TRY(ctx, launch_pad_fill(const_cast<float4*>(h_clouds[c].xyz), h_clouds[c].n,
                                    h_clouds[c].n_pad, st));
-  HIP_TRY(ctx, launch_index_fill(W->d_isegs.p, (int)h_isegs.size(), max_iseg_n, st));
+  HIP_TRY(ctx, launch_index_fill(d_isegs, (int)h_isegs.size(), max_iseg_n, st));
   // no previous match to seed the first lookup with
-  HIP_TRY(ctx, launch_keys_fill(W->d_pairs.p, W->d_state.p, n_pairs, max_src_n, true, st));
+  HIP_TRY(ctx, launch_keys_fill(d_pairs, d_state, n_pairs, max_src_n, true, st));
   if (cfg.covariance_from_knn) {
     for (int c = 0; c < n_clouds; ++c)
       HIP_TRY(ctx, launch_cov_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
@@ -635,12 +657,12 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
       }
       if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(W->d_pairs.p, h_pairs.data(), sizeof(PairDev) * n_pairs,
+    HIP_TRY(ctx, hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDev) * n_pairs,
                                 hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(W->d_state.p, h_state.data(), sizeof(PairState) * n_pairs,
+    HIP_TRY(ctx, hipMemcpyAsync(d_state, h_state.data(), sizeof(PairState) * n_pairs,
                                 hipMemcpyHostToDevice, st));
   }
-  HIP_TRY(ctx, launch_guess_transform(W->d_clouds.p, W->d_pairs.p, n_pairs, max_src_n, st));
+  HIP_TRY(ctx, launch_guess_transform(d_clouds, d_pairs, n_pairs, max_src_n, st));
   HIP_TRY(ctx, hipEventRecord(ev_prep, st));
 
   // ---- GICP outer loop -----------------------------------------------------------------------
@@ -650,7 +672,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   sp.tf_epsilon = cfg.tf_epsilon;
   sp.max_iterations = cfg.iterations;
   sp.max_inner_iterations = cfg.optimizer_iterations;
-  int* d_done = W->d_ints.p + off_done;
+  int* d_done = d_ints + off_done;
   // One 1-NN pass over the pairs of the current block map.  Inside the GICP loop only matches
   // closer than the correspondence threshold are used (gicp.hpp:476), so the pruned search is
   // capped just above it; the pass after the loop is exact for every point.
@@ -658,38 +680,56 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   if (cfg.reserved[4] > 0)  // diagnostics only: a smaller cap drops correspondences
     nn_cap = 1e-6f * (float)cfg.reserved[4] * (float)cfg.reserved[4];
   auto nn_pass = [&](bool final_pass) -> hipError_t {
-    const int4* map = final_pass ? W->d_bmap_nn_all.p : W->d_bmap_nn.p;
+    const int4* map = final_pass ? d_bmap_nn_all : d_bmap_nn;
     const int n_map = final_pass ? n_all_nn : (int)h_bmap_nn.size();
     const bool split = final_pass ? all_split : any_split;
     if (!ctx->nn_exhaustive)
-      return launch_nn_pruned(W->d_clouds.p, W->d_pairs.p, W->d_state.p, map, n_map,
+      return launch_nn_pruned(d_clouds, d_pairs, d_state, map, n_map,
                               final_pass,
                               final_pass ? std::numeric_limits<float>::infinity() : nn_cap,
                               ctx->nn_r0sq, cfg.reserved[6] != 1, W->d_counters.p, st);
     if (split) {
-      hipError_t e = launch_keys_fill(W->d_pairs.p, W->d_state.p, n_pairs, max_src_n, final_pass, st);
+      hipError_t e = launch_keys_fill(d_pairs, d_state, n_pairs, max_src_n, final_pass, st);
       if (e != hipSuccess) return e;
     }
-    return launch_nn_search(W->d_clouds.p, W->d_pairs.p, W->d_state.p, map, n_map,
+    return launch_nn_search(d_clouds, d_pairs, d_state, map, n_map,
                             final_pass, split, ctx->nn_variant, st);
   };
   std::vector<int> active;
   for (int p = 0; p < n_pairs; ++p)
     if (h_state[p].active) active.push_back(p);
   const int n_inactive0 = n_pairs - (int)active.size();
+  // Live block maps are rewritten from one of two alternating pinned staging buffers with a
+  // single copy (the reduce map's region is directly followed by the 1-NN map's).
+  const size_t red_region = o_nn - o_red;
+  int stage_k = 0;
+  auto upload_maps = [&]() -> int {
+    const size_t bytes = red_region + sizeof(int4) * h_bmap_nn.size();
+    const int k = stage_k;
+    stage_k ^= 1;
+    if (W->h_maps_cap[k] < bytes) {
+      if (W->h_maps[k]) (void)hipHostFree(W->h_maps[k]);
+      W->h_maps[k] = nullptr;
+      W->h_maps_cap[k] = 0;
+      const size_t want = red_region + sizeof(int4) * std::max(max_nn_blocks, (size_t)n_all_nn) + 4096;
+      HIP_TRY(ctx, hipHostMalloc((void**)&W->h_maps[k], want, hipHostMallocDefault));
+      W->h_maps_cap[k] = want;
+    }
+    char* h = reinterpret_cast<char*>(W->h_maps[k]);
+    std::memcpy(h, h_bmap_red.data(), sizeof(int4) * h_bmap_red.size());
+    std::memcpy(h + red_region, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size());
+    HIP_TRY(ctx, hipMemcpyAsync(d_bmap_red, h, bytes, hipMemcpyHostToDevice, st));
+    return LGICP_OK;
+  };
   if (n_inactive0) {
     build_maps(active);
-    HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_nn.p, h_bmap_nn.data(),
-                                sizeof(int4) * h_bmap_nn.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_red.p, h_bmap_red.data(),
-                                sizeof(int4) * h_bmap_red.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int rc = upload_maps();
+    if (rc != LGICP_OK) return rc;
   }
+  size_t mapped_active = active.size();
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_ev, red_ev, sol_ev;
   std::vector<int> h_flags((size_t)n_pairs + 1, 0);
   int outer = 0, done_seen = 0;
-  std::vector<int4> stage_nn[2], stage_red[2];
-  int stage_k = 0;
   // The host stays one iteration behind the device: iteration i+1 is enqueued before the
   // "done" flags of iteration i are looked at, so the device never waits for the round trip.
   // Pairs that have left the loop are skipped by the kernels themselves (PairState::active);
@@ -701,11 +741,11 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     HIP_TRY(ctx, hipEventRecord(a, st));
     HIP_TRY(ctx, nn_pass(false));
     HIP_TRY(ctx, hipEventRecord(b, st));
-    HIP_TRY(ctx, launch_gicp_reduce(W->d_clouds.p, W->d_pairs.p, W->d_state.p,
-                                    W->d_bmap_red.p, (int)h_bmap_red.size(), sp.corr_dist2,
+    HIP_TRY(ctx, launch_gicp_reduce(d_clouds, d_pairs, d_state,
+                                    d_bmap_red, (int)h_bmap_red.size(), sp.corr_dist2,
                                     W->d_partials.p, st));
     HIP_TRY(ctx, hipEventRecord(c, st));
-    HIP_TRY(ctx, launch_gicp_solve(W->d_pairs.p, W->d_state.p, n_pairs, W->d_ints.p,
+    HIP_TRY(ctx, launch_gicp_solve(d_pairs, d_state, n_pairs, d_ints,
                                    W->d_partials.p, sp, d_done, st));
     HIP_TRY(ctx, hipEventRecord(d, st));
     // the flags travel on their own stream: the next iteration does not queue up behind the copy
@@ -746,20 +786,14 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
         active.clear();
         for (int p = 0; p < n_pairs; ++p)
           if (h_state[p].active && !flags[1 + p]) active.push_back(p);
-        if (!active.empty()) {
+        // A staging buffer is reused two uploads later; each upload is followed in the stream
+        // by the next iteration's flag event, which the host has waited for by then.  Small
+        // changes are not worth a copy: blocks of finished pairs exit at once anyway.
+        if (!active.empty() && active.size() * 8 <= mapped_active * 7) {
           build_maps(active);
-          // Staged through two alternating host copies: an upload is followed in the stream by
-          // the next iteration's flag event, which the host has waited for before the same
-          // staging copy is written again.
-          std::vector<int4>& s_nn = stage_nn[stage_k];
-          std::vector<int4>& s_red = stage_red[stage_k];
-          stage_k ^= 1;
-          s_nn = h_bmap_nn;
-          s_red = h_bmap_red;
-          HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_nn.p, s_nn.data(), sizeof(int4) * s_nn.size(),
-                                      hipMemcpyHostToDevice, st));
-          HIP_TRY(ctx, hipMemcpyAsync(W->d_bmap_red.p, s_red.data(), sizeof(int4) * s_red.size(),
-                                      hipMemcpyHostToDevice, st));
+          rc = upload_maps();
+          if (rc != LGICP_OK) return rc;
+          mapped_active = active.size();
         }
       }
       if (!enqueued) {
@@ -776,8 +810,8 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   HIP_TRY(ctx, hipEventRecord(ev_post0, st));
   HIP_TRY(ctx, nn_pass(true));
   HIP_TRY(ctx, hipEventRecord(ev_post1, st));
-  HIP_TRY(ctx, launch_post_reduce(W->d_clouds.p, W->d_pairs.p, W->d_state.p,
-                                  W->d_bmap_red_all.p, n_all_red, W->d_partials.p,
+  HIP_TRY(ctx, launch_post_reduce(d_clouds, d_pairs, d_state,
+                                  d_bmap_red_all, n_all_red, W->d_partials.p,
                                   cfg.covariance_method == LGICP_COV_POINT2POINT &&
                                       !cfg.use_fixed_covariances,
                                   st));
@@ -785,7 +819,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   std::vector<double> h_post((size_t)n_pairs * RED_MAX_CHUNKS * NPOST);
   HIP_TRY(ctx, hipMemcpyAsync(h_post.data(), W->d_partials.p, sizeof(double) * h_post.size(),
                               hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(h_state.data(), W->d_state.p, sizeof(PairState) * n_pairs,
+  HIP_TRY(ctx, hipMemcpyAsync(h_state.data(), d_state, sizeof(PairState) * n_pairs,
                               hipMemcpyDeviceToHost, st));
   std::vector<unsigned long long> h_counters(NN_COUNTER_SLOTS, 0);
   HIP_TRY(ctx, hipMemcpyAsync(h_counters.data(), W->d_counters.p,

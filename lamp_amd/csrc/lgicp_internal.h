@@ -80,15 +80,13 @@ struct BatchSlot {
   hipStream_t stream = nullptr;
   hipStream_t flag_stream = nullptr;  // carries the "done" flags back to the host
   DevBuf<char> arena;                 // per-batch scratch (bump allocated)
-  DevBuf<CloudDev> d_clouds;
-  DevBuf<PairDev> d_pairs;
-  DevBuf<PairState> d_state;
-  DevBuf<SegmentDev> d_segs;
-  DevBuf<int4> d_bmap_nn, d_bmap_red;          // block maps of the pairs still in the loop
-  DevBuf<int4> d_bmap_nn_all, d_bmap_red_all;  // block maps of every pair of the batch
-  DevBuf<int> d_ints;  // n_chunks[n_pairs] | n_done, done flags | scan1 ids
+  // clouds, pairs, states, segments, chunk counts + done flags, block maps: one buffer, one copy
+  DevBuf<char> d_params;
+  char* h_params = nullptr;  // pinned staging of the same
+  size_t h_params_cap = 0;
+  int4* h_maps[2] = {nullptr, nullptr};  // pinned staging of the block maps rebuilt in the loop
+  size_t h_maps_cap[2] = {0, 0};
   DevBuf<double> d_partials;
-  DevBuf<IndexSegDev> d_isegs;
   DevBuf<unsigned long long> d_counters;
   int* h_done = nullptr;  // pinned, 2 x 32768
   std::vector<hipEvent_t> ev_pool;
@@ -111,9 +109,12 @@ struct BatchSlot {
   void destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (flag_stream) (void)hipStreamSynchronize(flag_stream);
-    arena.release(), d_clouds.release(), d_pairs.release(), d_state.release(), d_segs.release();
-    d_bmap_nn.release(), d_bmap_red.release(), d_bmap_nn_all.release(), d_bmap_red_all.release();
-    d_ints.release(), d_partials.release(), d_isegs.release(), d_counters.release();
+    arena.release(), d_params.release(), d_partials.release(), d_counters.release();
+    if (h_params) (void)hipHostFree(h_params);
+    for (int k = 0; k < 2; ++k)
+      if (h_maps[k]) (void)hipHostFree(h_maps[k]);
+    h_params = nullptr, h_maps[0] = h_maps[1] = nullptr;
+    h_params_cap = h_maps_cap[0] = h_maps_cap[1] = 0;
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     ev_pool.clear();
     if (h_done) (void)hipHostFree(h_done);
