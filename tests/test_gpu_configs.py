@@ -1,0 +1,102 @@
+"""The benchmark configurations as parity cases: one pair of every keyframe size the configs name
+(10k, 16k, 32k, 64k points) through lgicp_submit against the CPU oracle, and size-independent
+properties of a larger batch (batch independence, slot independence, pose-inverse consistency)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot_err(Ta, Tb):
+    # inv(Ta) @ Tb: exactly the identity for equal inputs (a transposed float rotation is not
+    # its exact inverse, which would show up as ~1e-4 rad through the arccos)
+    dT = np.linalg.inv(np.asarray(Ta, np.float64)) @ np.asarray(Tb, np.float64)
+    ang = np.arccos(np.clip((np.trace(dT[:3, :3]) - 1) / 2, -1, 1))
+    return ang, np.linalg.norm(dT[:3, 3])
+
+
+def _oracle_pair(work, a, b, solver):
+    src, sn = work.keyframes[a]
+    tgt, tn = work.keyframes[b]
+    params = O.base_icp_params(init_method=O.INIT_IDENTITY, solver=solver, threads=8,
+                               transform_thresholding=0)
+    ident = O.pose_from_quat([1, 0, 0, 0], [0, 0, 0])
+    return O.perform_alignment(params, src, sn, tgt, tn, src, tn, ident)
+
+
+@pytest.mark.parametrize("config,points", [("C1", None), ("C2", None), ("C3", None), ("C5", None)])
+def test_one_pair_of_each_configuration(config, points):
+    """north_star tolerances: pose 1e-4 rad / 1e-4 m, fitness and information 1e-5 relative
+    (against the oracle's Gauss-Newton back end; 1e-3 against its BFGS back end, the measured
+    distance between the two solvers' stopping points)."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload(config, pairs=2, keyframes=2)
+    c = capi.Context(init_method=capi.INIT_IDENTITY, transform_thresholding=0)
+    try:
+        work.register(c)
+        res = [capi.result_to_dict(r) for r in c.submit(work.candidates())]
+    finally:
+        c.close()
+    for d, (a, b) in zip(res, work.pairs):
+        gn = _oracle_pair(work, a, b, O.SOLVER_GN)
+        assert d["status"] == gn["status"] == 0
+        ang, te = _rot_err(gn["T_icp"], d["T_icp"])
+        assert ang < 1e-4 and te < 1e-4, (config, ang, te)
+        assert abs(d["fitness"] - gn["fitness"]) <= 1e-5 * gn["fitness"]
+        assert np.allclose(d["covariance"], gn["covariance"], rtol=1e-4,
+                           atol=1e-5 * np.abs(gn["covariance"]).max())
+        src, sn = work.keyframes[a]
+        tgt, tn = work.keyframes[b]
+        _, idx = O.fitness_score(src, tgt, d["T_icp"])
+        _, Ap = O.icp_cov_point_plane(src, tn, idx, d["T_icp"])
+        assert np.allclose(d["information"], Ap / 0.0025, rtol=1e-5,
+                           atol=1e-5 * np.abs(Ap).max() / 0.0025)
+        # the alignment is close to the synthetic truth (sanity, not parity)
+        ang, te = _rot_err(work.truth[(a, b)], d["T_icp"])
+        assert ang < 5e-3 and te < 2e-2
+    if config == "C1":      # the reference's own solver on its CPU-runnable configuration
+        a, b = work.pairs[0]
+        bf = _oracle_pair(work, a, b, O.SOLVER_BFGS)
+        ang, te = _rot_err(bf["T_icp"], res[0]["T_icp"])
+        assert ang < 1e-3 and te < 1e-3
+
+
+def test_batch_and_slot_independence():
+    """A pair's result does not depend on what else is in the submit, on the order of the
+    candidates, or on how the submit is cut over the two concurrent batch slots."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C2", pairs=96, points=4096, keyframes=16)
+    cands = work.candidates()
+
+    def run(cand_list, slots):
+        res = [0] * 8
+        res[7] = slots
+        c = capi.Context(init_method=capi.INIT_IDENTITY, reserved=(capi.C.c_int * 8)(*res))
+        try:
+            work.register(c)
+            return [capi.result_to_dict(r) for r in c.submit(cand_list)]
+        finally:
+            c.close()
+
+    two = run(cands, 2)
+    one = run(cands, 1)
+    rev = run(cands[::-1], 2)[::-1]
+    solo = run(cands[5:6], 1)
+    for a, b, r in zip(two, one, rev):
+        for other in (b, r):
+            assert a["status"] == other["status"] and a["iterations"] == other["iterations"]
+            assert np.array_equal(a["T_icp"], other["T_icp"])
+            assert a["fitness"] == other["fitness"]
+            assert np.array_equal(a["information"], other["information"])
+    assert np.array_equal(solo[0]["T_icp"], two[5]["T_icp"])
+    assert sum(r["status"] == 0 for r in two) >= 90
+    # edge transform = inverse of the ICP transform (gu::PoseInverse, IcpLoopComputation.cc:617)
+    for r in two:
+        if r["status"] == 0:
+            T = np.asarray(r["T_icp"], np.float64)
+            assert np.allclose(r["delta_R"] @ T[:3, :3], np.eye(3), atol=1e-6)
+            assert np.allclose(r["delta_R"] @ T[:3, 3] + r["delta_t"], 0, atol=1e-6)
