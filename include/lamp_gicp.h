@@ -231,6 +231,20 @@ int lgicp_sac_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const floa
                                 size_t n_tgt, const float guess[16], float T_out[16],
                                 double* fitness_score);
 
+/* lamp_utils::ComputeNormals, search_method 0 (PointCloudUtils.h:38-62; called for every keyed
+ * scan at factor_handlers/src/PoseGraphHandler.cc:188-196 and, through ExtractNormals, whenever a
+ * cloud arrives without normals, PointCloudUtils.cc:17-35): pcl::NormalEstimation over the k
+ * nearest neighbours (1..32; the reference uses 10), viewpoint at the origin.  normals is
+ * [n][3]; curvature (may be NULL) is [n]. */
+int lgicp_compute_normals(lgicp_ctx* ctx, const float* xyz, size_t n, int k, float* normals,
+                          float* curvature);
+
+/* lamp_utils::ComputeIcpObservability (PointCloudUtils.cc:165-196): ascending eigenvalues of the
+ * translational 3x3 block of Ap computed on the normalised cloud against its own (extracted)
+ * normals. */
+int lgicp_icp_observability(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
+                            double eigenvalues[3]);
+
 /* IcpLoopComputation::GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081): the same
  * keypoint/descriptor front end, every source descriptor matched with its 5 nearest target
  * descriptors, TEASER++ (noise bound 0.5, GNC-TLS rotation, greedy max-clique inlier selection)

@@ -18,7 +18,7 @@ EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_
            "lgicp_submit", "lgicp_get_stats", "lgicp_nn_search", "lgicp_covariances_from_normals",
            "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh",
            "lgicp_harris_keypoints", "lgicp_sac_initial_alignment",
-           "lgicp_teaser_initial_alignment"]
+           "lgicp_teaser_initial_alignment", "lgicp_compute_normals", "lgicp_icp_observability"]
 
 
 class Config(C.Structure):
@@ -115,6 +115,10 @@ def lib():
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
             C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
             C.POINTER(C.c_int32)]
+        L.lgicp_compute_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                            C.c_void_p]
+        L.lgicp_icp_observability.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                              C.c_void_p]
         _lib = L
     return _lib
 
@@ -289,6 +293,19 @@ class Context:
             self._h, _ptr(a[0]), _ptr(a[1]), len(a[0]), _ptr(a[2]), _ptr(a[3]), len(a[2]), _ptr(g),
             _ptr(T), C.byref(used), C.byref(nm), C.byref(nc)))
         return T.reshape(4, 4), bool(used.value), nm.value, nc.value
+
+    def compute_normals(self, xyz, k=10):
+        x = _f32(xyz).reshape(-1, 3)
+        nrm = np.empty((len(x), 3), np.float32)
+        cur = np.empty(len(x), np.float32)
+        self._check(lib().lgicp_compute_normals(self._h, _ptr(x), len(x), int(k), _ptr(nrm), _ptr(cur)))
+        return nrm, cur
+
+    def icp_observability(self, xyz, normals):
+        x, nn = _f32(xyz).reshape(-1, 3), _f32(normals).reshape(-1, 3)
+        ev = np.empty(3, np.float64)
+        self._check(lib().lgicp_icp_observability(self._h, _ptr(x), _ptr(nn), len(x), _ptr(ev)))
+        return ev
 
     def compute_ap(self, query, ref_normals, corr, T, normalize=True):
         q, rn = _f32(query).reshape(-1, 3), _f32(ref_normals).reshape(-1, 3)

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
       const double a2 = (double)(((0.f * s.x + 0.f * s.y) + fac * s.z) + oz);
       double n0 = 0, n1 = 0, n2 = 0;
       if (j < S2.n) {
-        const float4 nn = S2.nrm[j];
+        const float4 nn = S2.nrm_x[j];
         n0 = nn.x;
         n1 = nn.y;
         n2 = nn.z;

@@ -1,4 +1,5 @@
-// knn_cov.hip — k-nearest-neighbour covariance estimation with plane regularisation.
+// knn_cov.hip — k-nearest-neighbour covariance estimation with plane regularisation, and the
+// k-nearest-neighbour surface normals of lamp_utils::ComputeNormals (same neighbour search).
 //
 // Replaces the k-NN branch of MultithreadedGICP::computeCovariances
 // (lamp_utils/include/lamp_utils/gicp.hpp:83-155): for every point the k nearest points of
@@ -16,10 +17,60 @@
 
 namespace lgicp {
 
-template <int K>
+// pcl::computeRoots2: roots of the quadratic left when one eigenvalue is zero
+__device__ __forceinline__ void roots2(float b, float c, float roots[3]) {
+  roots[0] = 0.f;
+  float d = b * b - 4.0f * c;
+  if (d < 0.0f) d = 0.0f;
+  const float sd = sqrtf(d);
+  roots[2] = 0.5f * (b + sd);
+  roots[1] = 0.5f * (b - sd);
+}
+
+// pcl::computeRoots: eigenvalues of a symmetric 3x3 (row-major m) in closed form, ascending
+__device__ void compute_roots(const float m[9], float roots[3]) {
+  const float c0 = m[0] * m[4] * m[8] + 2.0f * m[1] * m[2] * m[5] - m[0] * m[5] * m[5] -
+                   m[4] * m[2] * m[2] - m[8] * m[1] * m[1];
+  const float c1 = m[0] * m[4] - m[1] * m[1] + m[0] * m[8] - m[2] * m[2] + m[4] * m[8] - m[5] * m[5];
+  const float c2 = m[0] + m[4] + m[8];
+  if (fabsf(c0) < 1.1920929e-07f) {
+    roots2(c2, c1, roots);
+    return;
+  }
+  const float s_inv3 = 1.0f / 3.0f;
+  const float s_sqrt3 = sqrtf(3.0f);
+  const float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+  const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.0f) q = 0.0f;
+  const float rho = sqrtf(-a_over_3);
+  const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+  const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+  roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+  roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  float t;
+  if (roots[0] >= roots[1]) t = roots[0], roots[0] = roots[1], roots[1] = t;
+  if (roots[1] >= roots[2]) {
+    t = roots[1], roots[1] = roots[2], roots[2] = t;
+    if (roots[0] >= roots[1]) t = roots[0], roots[0] = roots[1], roots[1] = t;
+  }
+  if (roots[0] <= 0.0f) roots2(c2, c1, roots);
+}
+
+// MODE 0: GICP covariance (gicp.hpp:83-155) into out_d[n][6].
+// MODE 1: surface normal + curvature of pcl::NormalEstimation (lamp_utils::ComputeNormals,
+//         lamp_utils/include/lamp_utils/PointCloudUtils.h:38-62) into out_f[n] = (nx, ny, nz, curvature):
+//         single-pass float moments of the k neighbours in ascending distance order, smallest
+//         eigenvector by the closed-form roots + row cross products of pcl::eigen33, flipped
+//         towards the viewpoint (0, 0, 0).
+template <int K, int MODE>
 __global__ __launch_bounds__(NN_THREADS) void cov_knn_kernel(const float4* __restrict__ xyz, int n,
                                                              int n_pad, int k, double eps,
-                                                             double* __restrict__ cov6) {
+                                                             double* __restrict__ cov6,
+                                                             float4* __restrict__ out_f) {
   __shared__ __attribute__((aligned(16))) float lds[3 * NN_TILE];
   float* const lx = lds;
   float* const ly = lds + NN_TILE;
@@ -85,6 +136,74 @@ __global__ __launch_bounds__(NN_THREADS) void cov_knn_kernel(const float4* __res
     }
   }
   if (i >= n) return;
+
+  if (MODE == 1) {
+    float4 res = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+    if (k >= 3) {
+      float accu[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        if (s < k && bi[s] != 0x7FFFFFFF) {
+          const float4 p = xyz[bi[s]];
+          accu[0] += p.x * p.x;
+          accu[1] += p.x * p.y;
+          accu[2] += p.x * p.z;
+          accu[3] += p.y * p.y;
+          accu[4] += p.y * p.z;
+          accu[5] += p.z * p.z;
+          accu[6] += p.x;
+          accu[7] += p.y;
+          accu[8] += p.z;
+        }
+      }
+      const float fk = (float)k;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) accu[e] /= fk;
+      float cov[9];
+      cov[0] = accu[0] - accu[6] * accu[6];
+      cov[1] = cov[3] = accu[1] - accu[6] * accu[7];
+      cov[2] = cov[6] = accu[2] - accu[6] * accu[8];
+      cov[4] = accu[3] - accu[7] * accu[7];
+      cov[5] = cov[7] = accu[4] - accu[7] * accu[8];
+      cov[8] = accu[5] - accu[8] * accu[8];
+      float scale = 0.f;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) scale = fabsf(cov[e]) > scale ? fabsf(cov[e]) : scale;
+      if (scale <= 1.17549435e-38f) scale = 1.0f;
+      float sm[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) sm[e] = cov[e] / scale;
+      float roots[3];
+      compute_roots(sm, roots);
+      const float ev = roots[0] * scale;
+      sm[0] -= roots[0];
+      sm[4] -= roots[0];
+      sm[8] -= roots[0];
+      const float v1[3] = {sm[1] * sm[5] - sm[2] * sm[4], sm[2] * sm[3] - sm[0] * sm[5], sm[0] * sm[4] - sm[1] * sm[3]};
+      const float v2[3] = {sm[1] * sm[8] - sm[2] * sm[7], sm[2] * sm[6] - sm[0] * sm[8], sm[0] * sm[7] - sm[1] * sm[6]};
+      const float v3[3] = {sm[4] * sm[8] - sm[5] * sm[7], sm[5] * sm[6] - sm[3] * sm[8], sm[3] * sm[7] - sm[4] * sm[6]};
+      const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+      const float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+      const float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+      float nx, ny, nz, len;
+      if (l1 >= l2 && l1 >= l3)
+        nx = v1[0], ny = v1[1], nz = v1[2], len = l1;
+      else if (l2 >= l1 && l2 >= l3)
+        nx = v2[0], ny = v2[1], nz = v2[2], len = l2;
+      else
+        nx = v3[0], ny = v3[1], nz = v3[2], len = l3;
+      const float r = sqrtf(len);
+      nx /= r, ny /= r, nz /= r;
+      const float eig_sum = cov[0] + cov[4] + cov[8];
+      const float curv = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
+      const float vx = 0.f - qx, vy = 0.f - qy, vz = 0.f - qz;
+      const float cos_theta = vx * nx + vy * ny + vz * nz;
+      if (cos_theta < 0.f) nx *= -1.f, ny *= -1.f, nz *= -1.f;
+      res = make_float4(nx, ny, nz, curv);
+    }
+    out_f[i] = res;
+    return;
+  }
 
   double mean[3] = {0, 0, 0}, c00 = 0, c10 = 0, c11 = 0, c20 = 0, c21 = 0, c22 = 0;
 #pragma unroll
@@ -166,11 +285,25 @@ hipError_t launch_cov_knn(const float4* xyz, int n, int n_pad, int k, double eps
   if (k < 1 || k > 32) return hipErrorInvalidValue;
   const dim3 grid((n + NN_THREADS - 1) / NN_THREADS), block(NN_THREADS);
   if (k <= 10)
-    hipLaunchKernelGGL(cov_knn_kernel<10>, grid, block, 0, stream, xyz, n, n_pad, k, eps, cov6);
+    hipLaunchKernelGGL((cov_knn_kernel<10, 0>), grid, block, 0, stream, xyz, n, n_pad, k, eps, cov6, nullptr);
   else if (k <= 20)
-    hipLaunchKernelGGL(cov_knn_kernel<20>, grid, block, 0, stream, xyz, n, n_pad, k, eps, cov6);
+    hipLaunchKernelGGL((cov_knn_kernel<20, 0>), grid, block, 0, stream, xyz, n, n_pad, k, eps, cov6, nullptr);
   else
-    hipLaunchKernelGGL(cov_knn_kernel<32>, grid, block, 0, stream, xyz, n, n_pad, k, eps, cov6);
+    hipLaunchKernelGGL((cov_knn_kernel<32, 0>), grid, block, 0, stream, xyz, n, n_pad, k, eps, cov6, nullptr);
+  return hipGetLastError();
+}
+
+hipError_t launch_normals_knn(const float4* xyz, int n, int n_pad, int k, float4* normals_curv,
+                              hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (k < 1 || k > 32) return hipErrorInvalidValue;
+  const dim3 grid((n + NN_THREADS - 1) / NN_THREADS), block(NN_THREADS);
+  if (k <= 10)
+    hipLaunchKernelGGL((cov_knn_kernel<10, 1>), grid, block, 0, stream, xyz, n, n_pad, k, 0.0, nullptr, normals_curv);
+  else if (k <= 20)
+    hipLaunchKernelGGL((cov_knn_kernel<20, 1>), grid, block, 0, stream, xyz, n, n_pad, k, 0.0, nullptr, normals_curv);
+  else
+    hipLaunchKernelGGL((cov_knn_kernel<32, 1>), grid, block, 0, stream, xyz, n, n_pad, k, 0.0, nullptr, normals_curv);
   return hipGetLastError();
 }
 

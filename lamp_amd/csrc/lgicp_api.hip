@@ -105,6 +105,11 @@ int build_keyframe_derived(lgicp_ctx* ctx, Keyframe* kf) {
   if (n == 0) return LGICP_OK;
   HIP_TRY(ctx, hipMalloc((void**)&kf->d_cov, sizeof(double) * 6 * (size_t)n));
   HIP_TRY(ctx, launch_cov_from_normals(kf->d_nrm, n, kf->d_cov, ctx->stream));
+  kf->d_nrm_x = kf->d_nrm;
+  if (kf->normals_missing) {  // ExtractNormals falls back to ComputeNormals (k = 10)
+    HIP_TRY(ctx, hipMalloc((void**)&kf->d_nrm_x, sizeof(float4) * (size_t)n));
+    HIP_TRY(ctx, launch_normals_knn(kf->d_xyz, n, kf->n_pad, std::min(10, n), kf->d_nrm_x, ctx->stream));
+  }
   CloudDev c;
   std::memset(&c, 0, sizeof(c));
   c.xyz = kf->d_xyz, c.n = n, c.n_pad = kf->n_pad;
@@ -240,6 +245,7 @@ int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const flo
   }
   for (size_t i = n; i < (size_t)kf.n_pad; ++i)
     hx[i] = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 1.0f);
+  kf.normals_missing = n > 0 && hn[0].x == 0.f && hn[0].y == 0.f && hn[0].z == 0.f;
   HIP_TRY(ctx, hipMalloc((void**)&kf.d_xyz, sizeof(float4) * (size_t)kf.n_pad));
   HIP_TRY(ctx, hipMalloc((void**)&kf.d_nrm, sizeof(float4) * std::max<size_t>(n, 1)));
   HIP_TRY(ctx, hipMemcpy(kf.d_xyz, hx.data(), sizeof(float4) * (size_t)kf.n_pad,
@@ -325,7 +331,7 @@ int plan_cloud(lgicp_ctx* ctx, BatchPlan& bp, uint64_t key, bool accumulate) {
   cp.n_pad = std::max(NN_TILE, round_up(cp.n, NN_TILE));
   if (acc || ctx->cfg.covariance_from_knn) bp.bytes += (size_t)cp.n * 48 + 256;  // covariances
   if (acc) {
-    bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 16 + 512;  // xyz + normals
+    bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 32 + 1024;  // xyz + normals (+ estimated)
     // spatial index: tile-ordered points, boxes, visiting order
     bp.bytes += (size_t)cp.n * 22 + (cp.segs.size() + 1) * (SI_TILE * 16 + 64) + 2048;
   }
@@ -361,6 +367,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   std::vector<CloudDev> h_clouds((size_t)n_clouds);
   std::vector<SegmentDev> h_segs;
   std::vector<IndexSegDev> h_isegs;
+  std::vector<int> normal_jobs;  // accumulated clouds whose normals have to be estimated
   int max_seg_n = 0, max_cloud_n = 0, max_iseg_n = 0;
   for (int c = 0; c < n_clouds; ++c) {
     CloudPlan& cp = bp.clouds[c];
@@ -375,6 +382,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     if (!cp.accumulated) {
       cd.xyz = kf.d_xyz;
       cd.nrm = kf.d_nrm;
+      cd.nrm_x = kf.d_nrm_x;
       std::memcpy(cd.centroid, kf.centroid, sizeof(cd.centroid));
       cd.factor = kf.factor;
       cd.sxyz = kf.d_sxyz, cd.tmin = kf.d_tmin, cd.tmax = kf.d_tmax, cd.qorder = kf.d_qorder;
@@ -384,6 +392,15 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
       float4* nrm = ar.take<float4>((size_t)cp.n);
       cd.xyz = xyz;
       cd.nrm = nrm;
+      cd.nrm_x = nrm;
+      if (kf.normals_missing && (cfg.init_method == LGICP_INIT_FEATURES ||
+                                 cfg.init_method == LGICP_INIT_TEASERPP)) {
+        // the feature front end extracts normals from the accumulated cloud
+        // (IcpLoopComputation.cc:654-658): recomputed over all of its points
+        float4* nx = ar.take<float4>((size_t)cp.n);
+        cd.nrm_x = nx;
+        normal_jobs.push_back(c);
+      }
       {  // index = concatenation of the member keyframes' segments
         int tiles = (kf.n + SI_TILE - 1) / SI_TILE;
         for (auto& sg : cp.segs) tiles += (ctx->scans.at(sg.first).n + SI_TILE - 1) / SI_TILE;
@@ -602,6 +619,10 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   HIP_TRY(ctx, launch_index_fill(d_isegs, (int)h_isegs.size(), max_iseg_n, st));
   // no previous match to seed the first lookup with
   HIP_TRY(ctx, launch_keys_fill(d_pairs, d_state, n_pairs, max_src_n, true, st));
+  for (int c : normal_jobs)
+    HIP_TRY(ctx, launch_normals_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
+                                    std::min(10, h_clouds[c].n),
+                                    const_cast<float4*>(h_clouds[c].nrm_x), st));
   if (cfg.covariance_from_knn) {
     for (int c = 0; c < n_clouds; ++c)
       HIP_TRY(ctx, launch_cov_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
@@ -621,7 +642,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     for (int p = 0; p < n_pairs; ++p)
       for (int c : {bp.pairs[p].src_cloud, bp.pairs[p].tgt_cloud})
         if (!feats.count(c)) {
-          const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm,
+          const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm_x,
                                                 h_clouds[c].n, &feats[c]);
           if (rc != LGICP_OK) return rc;
         }

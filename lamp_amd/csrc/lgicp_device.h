@@ -36,7 +36,9 @@ static constexpr int NPOST = 24;
 
 struct CloudDev {
   const float4* xyz;  // n_pad points (x, y, z, 1), tail = PAD_COORD
-  const float4* nrm;  // n normals (x, y, z, 0)
+  const float4* nrm;  // n normals (x, y, z, 0) as stored with the points
+  const float4* nrm_x;  // lamp_utils::ExtractNormals of the cloud: nrm, or k-NN normals when the
+                        // first stored normal is all zero (PointCloudUtils.cc:17-35)
   const double* cov;  // n x 6: c00 c01 c02 c11 c12 c22
   int n;
   int n_pad;
@@ -161,6 +163,9 @@ hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, cons
 
 hipError_t launch_cov_knn(const float4* xyz, int n, int n_pad, int k, double eps, double* cov6,
                           hipStream_t stream);
+// pcl::NormalEstimation with a k-NN search: normals_curv[n] = (nx, ny, nz, curvature)
+hipError_t launch_normals_knn(const float4* xyz, int n, int n_pad, int k, float4* normals_curv,
+                              hipStream_t stream);
 
 // FPFH at n_key keypoints over a surface of n points (radius^2 = r2); need[n], spfh[n*33]
 // are scratch, out is [n_key][33]

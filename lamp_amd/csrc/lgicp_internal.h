@@ -36,12 +36,18 @@ struct Keyframe {
   // derived once at registration: covariances from the normals (gicp_utils.h:28-62) and the
   // NormalizePCloud constants (PointCloudUtils.cc:39-59); both depend on the keyframe alone
   double* d_cov = nullptr;  // n x 6
+  // lamp_utils::ExtractNormals of the keyframe: d_nrm itself, or k-NN normals (own buffer) when
+  // the first stored normal is all zero
+  float4* d_nrm_x = nullptr;
+  bool normals_missing = false;
   float centroid[3] = {0.f, 0.f, 0.f};
   float factor = 0.f;
   void free_device() {
+    if (d_nrm_x == d_nrm) d_nrm_x = nullptr;
     for (void* p : {(void*)d_xyz, (void*)d_nrm, (void*)d_order, (void*)d_sxyz, (void*)d_tmin,
-                    (void*)d_tmax, (void*)d_qorder, (void*)d_cov})
+                    (void*)d_tmax, (void*)d_qorder, (void*)d_cov, (void*)d_nrm_x})
       if (p) (void)hipFree(p);
+    d_nrm_x = nullptr;
     d_xyz = d_nrm = d_sxyz = d_tmin = d_tmax = nullptr;
     d_order = d_qorder = nullptr;
     d_cov = nullptr;

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "lgicp_internal.h"
+#include "sac_ia.h"
 
 namespace {
 
@@ -204,7 +205,7 @@ int lgicp_compute_ap(lgicp_ctx* ctx, const float* query_xyz, size_t n_query,
   CloudDev hc[2];
   std::memset(hc, 0, sizeof(hc));
   hc[0].xyz = d_q, hc[0].n = (int)n_query, hc[0].n_pad = (int)n_query, hc[0].factor = 1.f;
-  hc[1].nrm = d_n, hc[1].n = (int)n_ref;
+  hc[1].nrm = d_n, hc[1].nrm_x = d_n, hc[1].n = (int)n_ref;
   PairDev hp;
   std::memset(&hp, 0, sizeof(hp));
   hp.src_cloud = 0, hp.tgt_cloud = 1, hp.scan1_cloud = 0, hp.scan2_cloud = 1;
@@ -300,6 +301,60 @@ int lgicp_sac_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const floa
   if (rc == LGICP_OK) rc = compute_cloud_features(ctx, d_tx, d_tn, (int)n_tgt, &ft);
   if (rc != LGICP_OK) return rc;
   return sac_align_device(ctx, fs, ft, guess, 0x5AC1A000u, T_out, fitness_score);
+}
+
+int lgicp_compute_normals(lgicp_ctx* ctx, const float* xyz, size_t n, int k, float* normals,
+                          float* curvature) {
+  if (!ctx || (n && (!xyz || !normals))) return fail(ctx, LGICP_E_INVALID, "null argument");
+  if (k < 1 || k > 32) return fail(ctx, LGICP_E_INVALID, "k must be in 1..32");
+  if (n > (size_t)1 << 28) return fail(ctx, LGICP_E_INVALID, "cloud too large");
+  if (n == 0) return LGICP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  Dev d;
+  const int n_pad = std::max(NN_TILE, round_up((int)n, NN_TILE));
+  float4* d_x = upload_points(d, xyz, n, n_pad, 1.f);
+  float4* d_o = d.alloc<float4>(n);
+  if (!d_x || !d_o) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, launch_normals_knn(d_x, (int)n, n_pad, (int)std::min<size_t>((size_t)k, n), d_o,
+                                  ctx->stream));
+  std::vector<float4> h(n);
+  HIP_TRY(ctx, hipMemcpyAsync(h.data(), d_o, sizeof(float4) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; ++i) {
+    normals[3 * i] = h[i].x, normals[3 * i + 1] = h[i].y, normals[3 * i + 2] = h[i].z;
+    if (curvature) curvature[i] = h[i].w;
+  }
+  return LGICP_OK;
+}
+
+int lgicp_icp_observability(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
+                            double eigenvalues[3]) {
+  if (!ctx || !eigenvalues || (n && (!xyz || !normals)))
+    return fail(ctx, LGICP_E_INVALID, "null argument");
+  eigenvalues[0] = eigenvalues[1] = eigenvalues[2] = 0.0;
+  if (n == 0) return LGICP_OK;
+  // ExtractNormals (PointCloudUtils.cc:17-35): stored normals unless the first one is all zero
+  std::vector<float> computed;
+  const float* nrm = normals;
+  if (normals[0] == 0.f && normals[1] == 0.f && normals[2] == 0.f) {
+    computed.resize(3 * n);
+    const int rc = lgicp_compute_normals(ctx, xyz, n, 10, computed.data(), nullptr);
+    if (rc != LGICP_OK) return rc;
+    nrm = computed.data();
+  }
+  // every point corresponds with itself, identity transform (PointCloudUtils.cc:176-186)
+  std::vector<int32_t> corr(n);
+  for (size_t i = 0; i < n; ++i) corr[i] = (int32_t)i;
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double Ap[36];
+  const int rc = lgicp_compute_ap(ctx, xyz, n, nrm, n, corr.data(), n, I, 1, Ap);
+  if (rc != LGICP_OK) return rc;
+  double B[9], ev[3], V[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) B[a * 3 + b] = Ap[(3 + a) * 6 + 3 + b];
+  lgicp::sac::eig3(B, ev, V);  // ascending, as Eigen's SelfAdjointEigenSolver reports them
+  for (int a = 0; a < 3; ++a) eigenvalues[a] = ev[a];
+  return LGICP_OK;
 }
 
 int lgicp_teaser_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const float* src_normals,

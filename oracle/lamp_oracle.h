@@ -145,6 +145,16 @@ double lo_sac_ia(const float* src_kp, const float* src_feat, int n_src, const fl
                  const float* tgt_feat, int n_tgt, int max_iterations, int k_corr,
                  const float guess[16], uint32_t seed, float T_out[16]);
 
+/* ------------------------------------------------------------------ normal estimation */
+/* lamp_utils::ComputeNormals (PointCloudUtils.h:38-62), k-NN search; normals [n][3] */
+void lo_point_normal(const float* xyz, const int32_t* idx, int k, const float* query, float nrm[3],
+                     float* curvature);
+void lo_compute_normals(const float* xyz, int n, int k, float* normals, float* curvature,
+                        int threads);
+/* lamp_utils::ExtractNormals (PointCloudUtils.cc:17-35) */
+void lo_extract_normals(const float* xyz, const float* stored, int n, int k, float* normals,
+                        int threads);
+
 /* ------------------------------------------------------------------ TEASER++ (parity unpinned) */
 /* GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081) from the keypoints on; see
  * lo_teaser.c for the restated algorithm.  pairs is [count][2] = (source, target) keypoint ids */

@@ -321,6 +321,24 @@ def sac_initial_alignment(src, src_n, tgt, tgt_n, harris_radius=0.1, harris_thre
     return T, fit, (i, j)
 
 
+def compute_normals(xyz, k=10, threads=4):
+    """lamp_utils::ComputeNormals (k-NN search).  Returns normals [n][3], curvature [n]."""
+    xyz = _f32(xyz)
+    nrm = np.empty((len(xyz), 3), np.float32)
+    cur = np.empty(len(xyz), np.float32)
+    lib().lo_compute_normals(_p(xyz, C.c_float), len(xyz), k, _p(nrm, C.c_float),
+                             _p(cur, C.c_float), threads)
+    return nrm, cur
+
+
+def extract_normals(xyz, stored, k=10, threads=4):
+    xyz, stored = _f32(xyz), _f32(stored)
+    nrm = np.empty((len(xyz), 3), np.float32)
+    lib().lo_extract_normals(_p(xyz, C.c_float), _p(stored, C.c_float), len(xyz), k,
+                             _p(nrm, C.c_float), threads)
+    return nrm
+
+
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 

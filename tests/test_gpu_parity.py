@@ -548,3 +548,51 @@ def test_submit_exhaustive_and_pruned_agree():
         assert np.array_equal(a["T_icp"], b["T_icp"])
         assert a["fitness"] == b["fitness"]
         assert np.allclose(a["information"], b["information"], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ normals, observability
+def test_compute_normals_matches_oracle(ctx):
+    """lamp_utils::ComputeNormals (PointCloudUtils.h:38-62).  Pinned by the reference on the
+    plane fixture (test_point_cloud_utils.cc:39-52); elsewhere checked against the CPU
+    restatement of PCL's float algorithm (sinf/cosf/atan2f differ in the last bits between host
+    and device: 1e-4 on the components, looser where the smallest eigenvalue is degenerate)."""
+    plane, _ = F.generate_plane()
+    nrm, cur = ctx.compute_normals(plane, 10)
+    assert np.allclose(nrm, [0, 0, 1], atol=1e-5) and np.all(cur == 0)
+    xyz, _ = F.random_room_scan(6000, 12)
+    ref, rc = O.compute_normals(xyz, 10)
+    got, gc = ctx.compute_normals(xyz, 10)
+    err = np.abs(got - ref).max(1)
+    assert np.median(err) < 1e-5 and (err < 1e-3).mean() > 0.99, (np.median(err), err.max())
+    assert np.median(np.abs(gc - rc)) < 1e-6
+    assert np.allclose(np.linalg.norm(got, axis=1), 1, atol=1e-5)
+
+
+def test_icp_observability_known_values(ctx):
+    """TestPointCloudUtils.ComputeIcpObservability (test_point_cloud_utils.cc:172-181): the plane
+    constrains only its normal direction, eigenvalues (0, 0, 100)."""
+    plane, pn = F.generate_plane()
+    ev = ctx.icp_observability(plane, pn)
+    assert np.allclose(ev, [0, 0, 100], atol=1e-5)
+    assert np.allclose(ctx.icp_observability(plane, np.zeros_like(pn)), [0, 0, 100], atol=1e-4)
+    xyz, nrm = F.random_room_scan(5000, 13)
+    assert np.allclose(ctx.icp_observability(xyz, nrm), O.icp_observability(xyz, nrm), rtol=1e-6)
+
+
+def test_submit_with_missing_normals_uses_estimated_ones():
+    """ExtractNormals (PointCloudUtils.cc:17-35): a target keyframe whose first stored normal is
+    zero gets k-NN normals for the POINT2PLANE information matrix."""
+    from lamp_amd import capi
+    c = capi.Context(init_method=capi.INIT_IDENTITY, covariance_from_knn=1)
+    try:
+        src, sn, tgt, tn, _ = F.make_pair(4000, 91, rot_deg=2.0, trans=0.2)
+        _register(c, 10, tgt, np.zeros_like(tn))
+        _register(c, 20, src, sn)
+        d = capi.result_to_dict(c.submit([(20, 10)])[0])
+        assert d["status"] == 0
+        est = O.extract_normals(tgt, np.zeros_like(tn))
+        _, idx = O.fitness_score(src, tgt, d["T_icp"])
+        _, Ap = O.icp_cov_point_plane(src, est, idx, d["T_icp"])
+        assert np.allclose(d["information"], Ap / 0.0025, rtol=2e-3, atol=2e-3 * np.abs(Ap).max() / 0.0025)
+    finally:
+        c.close()

@@ -347,3 +347,25 @@ def test_teaser_initial_alignment_corner():
     g = np.eye(4, dtype=np.float32); g[0, 3] = 0.9
     T, used, n_matches, n_clique = O.teaser_initial_alignment(corner, cn, moved, mn, guess=g)
     assert n_matches == 9 and not used and np.array_equal(T, g)
+
+
+# ------------------------------------------------------------------ normal estimation
+def test_compute_normals_reference_plane():
+    """TestPointCloudUtils.ComputeNormals / ExtractNormals (test_point_cloud_utils.cc:39-68):
+    every normal of the 100-point plane is (0, 0, 1) within 1e-5."""
+    plane, pn = F.generate_plane()
+    nrm, cur = O.compute_normals(plane, 10)
+    assert nrm.shape == (100, 3)
+    assert np.allclose(nrm, [0, 0, 1], atol=1e-5) and np.all(cur == 0)
+    assert np.allclose(O.extract_normals(plane, pn), [0, 0, 1], atol=1e-5)
+    # a cloud that arrives without normals gets them estimated
+    assert np.allclose(O.extract_normals(plane, np.zeros_like(pn)), [0, 0, 1], atol=1e-5)
+
+
+def test_compute_normals_room():
+    xyz, true_n = F.random_room_scan(4000, 11)
+    nrm, cur = O.compute_normals(xyz, 10)
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-5)
+    assert np.all((nrm * -xyz).sum(1) >= -1e-6)              # flipped towards the origin
+    assert np.median(np.abs((nrm * true_n).sum(1))) > 0.99
+    assert np.all((cur >= 0) & (cur <= 1 / 3 + 1e-5))
