@@ -37,7 +37,9 @@ __global__ __launch_bounds__(RED_THREADS, 2) void gicp_reduce_kernel(
   // double-precision statistics: no float result of the reference is reproduced bit by bit
   // here, so multiply-adds may fuse (the float transformation arithmetic lives elsewhere)
 #pragma clang fp contract(fast)
-  __shared__ double sh[RED_THREADS / 64][NSTAT];
+  __shared__ double sh[RED_THREADS / 64][NSTAT + 6];
+  constexpr int RED_ROW = 4 * 17;  // 64 partials of one statistic, 4 groups of 16 padded to 17
+  __shared__ double transpose[RED_THREADS / 64][16 * RED_ROW];
   const int4 bm = bmap[blockIdx.x];
   const int pair = bm.x;
   const PairState& S = st[pair];
@@ -69,8 +71,12 @@ __global__ __launch_bounds__(RED_THREADS, 2) void gicp_reduce_kernel(
   const int per = (n + bm.z - 1) / bm.z;
   const int i0 = bm.y * per;
   const int i1 = min(n, i0 + per);
+  // the packed match of the next point is fetched one iteration ahead: the gathers that depend
+  // on it then start at the top of the iteration instead of a memory latency later
+  nnkey_t key_nxt = (i0 + (int)threadIdx.x < i1) ? P.keys[i0 + threadIdx.x] : NNKEY_NONE;
   for (int i = i0 + threadIdx.x; i < i1; i += RED_THREADS) {
-    const nnkey_t key = P.keys[i];
+    const nnkey_t key = key_nxt;
+    key_nxt = (i + RED_THREADS < i1) ? P.keys[i + RED_THREADS] : NNKEY_NONE;
     if (key == NNKEY_NONE) continue;
     const float d2 = __uint_as_float((unsigned)(key >> 32));
     if (!((double)d2 < corr_dist2)) continue;  // gicp.hpp:483
@@ -131,15 +137,31 @@ __global__ __launch_bounds__(RED_THREADS, 2) void gicp_reduce_kernel(
     ++m;
   }
 
+  // Wave-level sums through LDS, 16 statistics at a time: every lane stores its 16 partials
+  // (statistic-major, padded rows), then lane (v, part) = (lane / 4, lane % 4) adds the 16
+  // partials of statistic v that lanes 16*part .. 16*part+15 stored, and two shuffles combine the
+  // four parts.  74 x 6 dependent shuffle steps become 80 stores, 80 loads and 10 shuffles.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* const tr = transpose[wave];
+  const int v = lane >> 2, part = lane & 3;
 #pragma unroll
-  for (int i = 0; i < NSTAT - 1; ++i) {
-    const double v = wave_sum(acc[i]);
-    if (lane == 0) sh[wave][i] = v;
-  }
-  {
-    const double v = wave_sum((double)m);
-    if (lane == 0) sh[wave][NSTAT - 1] = v;
+  for (int c = 0; c < (NSTAT + 15) / 16; ++c) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = c * 16 + e;
+      const double val = idx < NSTAT - 1 ? acc[idx < NSTAT - 1 ? idx : 0] : (idx == NSTAT - 1 ? (double)m : 0.0);
+      tr[e * RED_ROW + (lane >> 4) * 17 + (lane & 15)] = val;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double sum = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) sum += tr[v * RED_ROW + part * 17 + t];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (part == 0 && c * 16 + v < NSTAT) sh[wave][c * 16 + v] = sum;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
   if (threadIdx.x < NSTAT) {
