@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--nn-variant", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the result gather even with one rank")
     ap.add_argument("--exhaustive", action="store_true",
                     help="use the exhaustive 1-NN kernel instead of the pruned one")
     args = ap.parse_args()
@@ -85,7 +87,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         # torch first: liblamp_gicp.so then binds to the HIP runtime torch has already loaded
         import torch
         import torch.distributed as dist
@@ -117,12 +119,12 @@ def main():
 
     def step():
         out = ctx.submit_packed(packed)     # blocking: returns after the device work is done
-        res = [out[i] for i in range(len(cands))]
         if dist is not None:
             import torch
-            gather_records(pack_results(res), dist, rank, world, torch.device("cuda", local_rank))
+            gather_records(pack_results(out, len(cands)), dist, rank, world,
+                           torch.device("cuda", local_rank), equal_counts=True)
             torch.cuda.synchronize()
-        return res
+        return out
 
     for _ in range(args.warmup):
         res = step()
@@ -153,6 +155,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    res = [res[i] for i in range(len(cands))]
     ok = sum(1 for r in res if r.status == 0)
     iters = [r.iterations for r in res]
     # accuracy of the last step against the known offsets (sanity, not a parity claim)

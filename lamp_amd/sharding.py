@@ -38,8 +38,22 @@ def partition_pairs(pairs, cloud_sizes, world):
     return out
 
 
-def pack_results(results):
-    """lgicp_result list -> [n, RESULT_WIDTH] float64 (keys are exact up to 2^53)."""
+def pack_results(results, n=None):
+    """lgicp_result array (the ctypes array lgicp_submit filled, or a list of results) ->
+    [n, RESULT_WIDTH] float64 (keys are exact up to 2^53)."""
+    import ctypes
+    if isinstance(results, ctypes.Array):
+        n = len(results) if n is None else n
+        rec = np.frombuffer(results, dtype=np.dtype(type(results)._type_), count=n)
+        out = np.zeros((n, RESULT_WIDTH), np.float64)
+        out[:, 0], out[:, 1] = rec["key_from"], rec["key_to"]
+        out[:, 2], out[:, 3], out[:, 4] = rec["status"], rec["iterations"], rec["fitness"]
+        out[:, 5:21] = rec["T_icp"]
+        out[:, 21:30] = rec["delta_R"]
+        out[:, 30:33] = rec["delta_t"]
+        out[:, 33:69] = rec["covariance"]
+        out[:, 69:105] = rec["information"]
+        return out
     out = np.zeros((len(results), RESULT_WIDTH), np.float64)
     for i, r in enumerate(results):
         row = out[i]
@@ -53,16 +67,21 @@ def pack_results(results):
     return out
 
 
-def gather_records(records, dist, rank, world, device=None):
-    """Gather per-rank [n_r, RESULT_WIDTH] arrays to rank 0 (ranks may hold different n_r).
+def gather_records(records, dist, rank, world, device=None, equal_counts=False):
+    """Gather per-rank [n_r, RESULT_WIDTH] arrays to rank 0 (ranks may hold different n_r;
+    equal_counts=True skips the count exchange when every rank is known to hold the same n).
     Returns the concatenated array on rank 0, None elsewhere."""
     import torch
-    if world == 1 or dist is None:
+    if dist is None:
         return records
     dev = torch.device("cpu") if device is None else device
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    counts[rank] = records.shape[0]
-    dist.all_reduce(counts)
+    if equal_counts:
+        counts = torch.full((world,), records.shape[0], dtype=torch.int64)
+    else:
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        counts[rank] = records.shape[0]
+        dist.all_reduce(counts)
+        counts = counts.cpu()
     n_max = int(counts.max().item())
     buf = torch.zeros((n_max, RESULT_WIDTH), dtype=torch.float64, device=dev)
     if records.shape[0]:
