@@ -100,3 +100,51 @@ def test_batch_and_slot_independence():
             T = np.asarray(r["T_icp"], np.float64)
             assert np.allclose(r["delta_R"] @ T[:3, :3], np.eye(3), atol=1e-6)
             assert np.allclose(r["delta_R"] @ T[:3, 3] + r["delta_t"], 0, atol=1e-6)
+
+
+def test_small_workspace_cuts_the_submit_into_sub_batches():
+    """workspace_bytes bounds the per-batch scratch (configuration C5 does not fit one batch):
+    the results do not depend on where the cuts fall."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C2", pairs=40, points=4096, keyframes=8)
+    outs = []
+    for ws in (0, 600_000):                       # default 16 GiB, then room for ~3 pairs
+        c = capi.Context(init_method=capi.INIT_IDENTITY, workspace_bytes=ws)
+        try:
+            work.register(c)
+            outs.append([capi.result_to_dict(r) for r in c.submit(work.candidates())])
+        finally:
+            c.close()
+    for a, b in zip(*outs):
+        assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
+        assert np.array_equal(a["T_icp"], b["T_icp"]) and a["fitness"] == b["fitness"]
+
+
+def test_robot_parameter_block():
+    """The reference's robot-side block (laser_parameters.yaml:5-147): corr_dist 0.1, 5 outer
+    iterations, fitness gate 0.4, no transform thresholding — pairs mostly stop at the
+    iteration limit, which counts as converged (gicp.hpp:564-580)."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C1", pairs=2, keyframes=2)
+    cfg = capi.default_config(False, init_method=capi.INIT_IDENTITY, accumulate_source=0)
+    c = capi.Context(cfg)
+    try:
+        work.register(c)
+        res = [capi.result_to_dict(r) for r in c.submit(work.candidates())]
+    finally:
+        c.close()
+    for d, (a, b) in zip(res, work.pairs):
+        src, sn = work.keyframes[a]
+        tgt, tn = work.keyframes[b]
+        params = O.base_icp_params(init_method=O.INIT_IDENTITY, solver=O.SOLVER_GN, threads=8,
+                                   corr_dist=0.1, max_iterations=5, max_tolerable_fitness=0.4,
+                                   transform_thresholding=0)
+        ref = O.perform_alignment(params, src, sn, tgt, tn, src, tn,
+                                  O.pose_from_quat([1, 0, 0, 0], [0, 0, 0]))
+        assert d["status"] == ref["status"]
+        assert d["iterations"] == ref["iterations"] <= 5
+        ang, te = _rot_err(ref["T_icp"], d["T_icp"])
+        assert ang < 1e-4 and te < 1e-4
+        assert abs(d["fitness"] - ref["fitness"]) <= 1e-5 * ref["fitness"]
