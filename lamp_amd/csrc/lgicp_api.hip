@@ -617,8 +617,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
       HIP_TRY(ctx, launch_pad_fill(const_cast<float4*>(h_clouds[c].xyz), h_clouds[c].n,
                                    h_clouds[c].n_pad, st));
   HIP_TRY(ctx, launch_index_fill(d_isegs, (int)h_isegs.size(), max_iseg_n, st));
-  // no previous match to seed the first lookup with
-  HIP_TRY(ctx, launch_keys_fill(d_pairs, d_state, n_pairs, max_src_n, true, st));
+
   for (int c : normal_jobs)
     HIP_TRY(ctx, launch_normals_knn(h_clouds[c].xyz, h_clouds[c].n, h_clouds[c].n_pad,
                                     std::min(10, h_clouds[c].n),
@@ -700,7 +699,10 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   float nn_cap = std::nextafter((float)sp.corr_dist2, std::numeric_limits<float>::infinity());
   if (cfg.reserved[4] > 0)  // diagnostics only: a smaller cap drops correspondences
     nn_cap = 1e-6f * (float)cfg.reserved[4] * (float)cfg.reserved[4];
+  bool have_matches = false;  // a previous pass has filled PairDev::keys: the next one may seed
   auto nn_pass = [&](bool final_pass) -> hipError_t {
+    const bool seed = have_matches && cfg.reserved[6] != 1;
+    have_matches = true;
     const int4* map = final_pass ? d_bmap_nn_all : d_bmap_nn;
     const int n_map = final_pass ? n_all_nn : (int)h_bmap_nn.size();
     const bool split = final_pass ? all_split : any_split;
@@ -708,7 +710,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
       return launch_nn_pruned(d_clouds, d_pairs, d_state, map, n_map,
                               final_pass,
                               final_pass ? std::numeric_limits<float>::infinity() : nn_cap,
-                              ctx->nn_r0sq, cfg.reserved[6] != 1, W->d_counters.p, st);
+                              ctx->nn_r0sq, seed, W->d_counters.p, st);
     if (split) {
       hipError_t e = launch_keys_fill(d_pairs, d_state, n_pairs, max_src_n, final_pass, st);
       if (e != hipSuccess) return e;
