@@ -18,79 +18,146 @@
 
 namespace lgicp {
 
-// nn[i][0..k) = indices of the k nearest target descriptors of source descriptor i
+// nn[i][0..k) = indices of the k nearest target descriptors of source descriptor i.
+// One lane per source descriptor (33 floats in registers); the target descriptors stream
+// through LDS in tiles of FK_TILE, padded to 36 floats so that a descriptor is read back with
+// nine wave-uniform (broadcast) ds_read_b128.
+constexpr int FK_TILE = 64;
+constexpr int FK_STRIDE = 36;
+
 __global__ __launch_bounds__(128) void feature_knn_kernel(const float* __restrict__ src_feat,
                                                           int n_src,
                                                           const float* __restrict__ tgt_feat,
                                                           int n_tgt, int k,
                                                           int* __restrict__ nn) {
+  __shared__ __attribute__((aligned(16))) float tile[FK_TILE * FK_STRIDE];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_src) return;
-  float f[33];
+  float f[36];
 #pragma unroll
-  for (int b = 0; b < 33; ++b) f[b] = src_feat[(size_t)i * 33 + b];
+  for (int b = 0; b < 36; ++b) f[b] = (b < 33 && i < n_src) ? src_feat[(size_t)i * 33 + b] : 0.f;
   float bd[8];
   int bi[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) bd[s] = __builtin_inff(), bi[s] = -1;
-  for (int j = 0; j < n_tgt; ++j) {
-    float d = 0;
+  for (int j0 = 0; j0 < n_tgt; j0 += FK_TILE) {
+    __syncthreads();
+    const int cnt = min(FK_TILE, n_tgt - j0);
+    for (int e = threadIdx.x; e < cnt * 33; e += blockDim.x)
+      tile[(e / 33) * FK_STRIDE + e % 33] = tgt_feat[(size_t)j0 * 33 + e];
+    __syncthreads();
+    for (int jj = 0; jj < cnt; ++jj) {
+      const float4* t4 = reinterpret_cast<const float4*>(tile + jj * FK_STRIDE);
+      float t[36];
 #pragma unroll
-    for (int b = 0; b < 33; ++b) {
-      const float e = f[b] - tgt_feat[(size_t)j * 33 + b];
-      d += e * e;
-    }
-    float worst = bd[0];
+      for (int q = 0; q < 9; ++q) {
+        const float4 v = t4[q];
+        t[4 * q] = v.x, t[4 * q + 1] = v.y, t[4 * q + 2] = v.z, t[4 * q + 3] = v.w;
+      }
+      float d = 0;
 #pragma unroll
-    for (int s = 1; s < 8; ++s)
-      if (s < k) worst = bd[s];
-    if (d < worst) {
-      float cd = d;
-      int ci = j;
+      for (int b = 0; b < 33; ++b) {
+        const float e = f[b] - t[b];
+        d += e * e;
+      }
+      const int j = j0 + jj;
+      float worst = bd[0];
 #pragma unroll
-      for (int s = 0; s < 8; ++s)
-        if (s < k) {
-          const bool lt = cd < bd[s];
-          const float td = lt ? bd[s] : cd;
-          const int ti = lt ? bi[s] : ci;
-          bd[s] = lt ? cd : bd[s];
-          bi[s] = lt ? ci : bi[s];
-          cd = td;
-          ci = ti;
-        }
+      for (int s = 1; s < 8; ++s)
+        if (s < k) worst = bd[s];
+      if (d < worst) {
+        float cd = d;
+        int ci = j;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          if (s < k) {
+            const bool lt = cd < bd[s];
+            const float td = lt ? bd[s] : cd;
+            const int ti = lt ? bi[s] : ci;
+            bd[s] = lt ? cd : bd[s];
+            bi[s] = lt ? ci : bi[s];
+            cd = td;
+            ci = ti;
+          }
+      }
     }
   }
-  for (int s = 0; s < k; ++s) nn[(size_t)i * k + s] = bi[s];
+  if (i < n_src)
+    for (int s = 0; s < k; ++s) nn[(size_t)i * k + s] = bi[s];
 }
 
-// one workgroup per hypothesis: err = sum min(d2/100, 1), fit = sum d2
-__global__ __launch_bounds__(256) void sac_score_kernel(const float* __restrict__ hyp,
-                                                        const float4* __restrict__ src_kp,
-                                                        int n_src,
-                                                        const float4* __restrict__ tgt_kp,
-                                                        int n_tgt, float threshold,
-                                                        double* __restrict__ err_fit) {
-  __shared__ double sh[2][4];
+// Scores hypotheses: workgroup (h, c) moves SS_QUERIES source keypoints (4 per lane) by
+// hypothesis h and sweeps every target keypoint through LDS tiles, two queries per packed
+// instruction; err = sum min(d2 / threshold, 1), fit = sum d2 of its chunk go to
+// err_fit[(h * n_chunks + c) * 2 + {0, 1}] and are added up in chunk order by the host.
+constexpr int SS_THREADS = 256;
+constexpr int SS_Q = 4;
+constexpr int SS_QUERIES = SS_THREADS * SS_Q;
+constexpr int SS_TILE = 512;
+typedef float ss_v2f __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(SS_THREADS) void sac_score_kernel(const float* __restrict__ hyp,
+                                                               const float4* __restrict__ src_kp,
+                                                               int n_src,
+                                                               const float4* __restrict__ tgt_kp,
+                                                               int n_tgt, float threshold,
+                                                               double* __restrict__ err_fit) {
+  __shared__ __attribute__((aligned(16))) float lx[SS_TILE], ly[SS_TILE], lz[SS_TILE];
+  __shared__ double sh[2][SS_THREADS / 64];
   const float* T = hyp + (size_t)blockIdx.x * 16;
   float t[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) t[i] = T[i];
-  double err = 0, fit = 0;
-  for (int i = threadIdx.x; i < n_src; i += 256) {
-    const float4 p = src_kp[i];
-    const float x = ((t[0] * p.x + t[1] * p.y) + t[2] * p.z) + t[3];
-    const float y = ((t[4] * p.x + t[5] * p.y) + t[6] * p.z) + t[7];
-    const float z = ((t[8] * p.x + t[9] * p.y) + t[10] * p.z) + t[11];
-    float best = __builtin_inff();
-    for (int j = 0; j < n_tgt; ++j) {
-      const float4 q = tgt_kp[j];
-      const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
-      const float d = (dx * dx + dy * dy) + dz * dz;
-      best = d < best ? d : best;
+  ss_v2f qx[SS_Q / 2], qy[SS_Q / 2], qz[SS_Q / 2];
+  float best[SS_Q];
+  bool have[SS_Q];
+#pragma unroll
+  for (int q = 0; q < SS_Q; ++q) {
+    const int i = blockIdx.y * SS_QUERIES + q * SS_THREADS + threadIdx.x;
+    have[q] = i < n_src;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (have[q]) {
+      const float4 p = src_kp[i];
+      x = ((t[0] * p.x + t[1] * p.y) + t[2] * p.z) + t[3];
+      y = ((t[4] * p.x + t[5] * p.y) + t[6] * p.z) + t[7];
+      z = ((t[8] * p.x + t[9] * p.y) + t[10] * p.z) + t[11];
     }
-    err += (double)((best <= threshold) ? best / threshold : 1.0f);  // TruncatedError
-    fit += (double)best;
+    qx[q / 2][q % 2] = x, qy[q / 2][q % 2] = y, qz[q / 2][q % 2] = z;
+    best[q] = __builtin_inff();
   }
+  for (int j0 = 0; j0 < n_tgt; j0 += SS_TILE) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < SS_TILE; j += SS_THREADS) {
+      // the tail of the last tile repeats the last target: it cannot change a minimum
+      const float4 p = tgt_kp[min(j0 + j, n_tgt - 1)];
+      lx[j] = p.x, ly[j] = p.y, lz[j] = p.z;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int j = 0; j < SS_TILE; j += 4) {
+      const float4 xa = *reinterpret_cast<const float4*>(lx + j);
+      const float4 ya = *reinterpret_cast<const float4*>(ly + j);
+      const float4 za = *reinterpret_cast<const float4*>(lz + j);
+      const float tx[4] = {xa.x, xa.y, xa.z, xa.w}, ty[4] = {ya.x, ya.y, ya.z, ya.w},
+                  tz[4] = {za.x, za.y, za.z, za.w};
+#pragma unroll
+      for (int p = 0; p < SS_Q / 2; ++p) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const ss_v2f dx = qx[p] - tx[e], dy = qy[p] - ty[e], dz = qz[p] - tz[e];
+          const ss_v2f d = (dx * dx + dy * dy) + dz * dz;
+          best[2 * p] = d.x < best[2 * p] ? d.x : best[2 * p];
+          best[2 * p + 1] = d.y < best[2 * p + 1] ? d.y : best[2 * p + 1];
+        }
+      }
+    }
+  }
+  double err = 0, fit = 0;
+#pragma unroll
+  for (int q = 0; q < SS_Q; ++q)
+    if (have[q]) {
+      err += (double)((best[q] <= threshold) ? best[q] / threshold : 1.0f);  // TruncatedError
+      fit += (double)best[q];
+    }
   for (int off = 32; off > 0; off >>= 1) {
     err += __shfl_xor(err, off);
     fit += __shfl_xor(fit, off);
@@ -99,8 +166,9 @@ __global__ __launch_bounds__(256) void sac_score_kernel(const float* __restrict_
   if (lane == 0) sh[0][wave] = err, sh[1][wave] = fit;
   __syncthreads();
   if (threadIdx.x == 0) {
-    err_fit[2 * (size_t)blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    err_fit[2 * (size_t)blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const size_t o = 2 * ((size_t)blockIdx.x * gridDim.y + blockIdx.y);
+    err_fit[o] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    err_fit[o + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   }
 }
 
@@ -187,15 +255,22 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
   const int n_hyp = (int)(hyp.T.size() / 16);
   if (n_hyp == 0) return LGICP_OK;
   float* d_hyp = d.alloc<float>(hyp.T.size());
-  double* d_ef = d.alloc<double>((size_t)2 * n_hyp);
+  const int n_chunks = (n_src + lgicp::SS_QUERIES - 1) / lgicp::SS_QUERIES;
+  double* d_ef = d.alloc<double>((size_t)2 * n_hyp * n_chunks);
   if (!d_hyp || !d_ef) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
   HIP_TRY(ctx, hipMemcpyAsync(d_hyp, hyp.T.data(), sizeof(float) * hyp.T.size(), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(lgicp::sac_score_kernel, dim3(n_hyp), dim3(256), 0, st, d_hyp, d_sk, n_src,
-                     d_tk, n_tgt, 100.0f, d_ef);
+  hipLaunchKernelGGL(lgicp::sac_score_kernel, dim3(n_hyp, n_chunks), dim3(lgicp::SS_THREADS), 0, st,
+                     d_hyp, d_sk, n_src, d_tk, n_tgt, 100.0f, d_ef);
   HIP_TRY(ctx, hipGetLastError());
-  std::vector<double> ef((size_t)2 * n_hyp);
-  HIP_TRY(ctx, hipMemcpyAsync(ef.data(), d_ef, sizeof(double) * ef.size(), hipMemcpyDeviceToHost, st));
+  std::vector<double> efc((size_t)2 * n_hyp * n_chunks);
+  HIP_TRY(ctx, hipMemcpyAsync(efc.data(), d_ef, sizeof(double) * efc.size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<double> ef((size_t)2 * n_hyp, 0.0);
+  for (int h = 0; h < n_hyp; ++h)
+    for (int c = 0; c < n_chunks; ++c) {
+      ef[2 * h] += efc[2 * ((size_t)h * n_chunks + c)];
+      ef[2 * h + 1] += efc[2 * ((size_t)h * n_chunks + c) + 1];
+    }
   // the sequential rule: hypothesis 0 always, afterwards only a strictly lower error
   int best = 0;
   float lowest = (float)ef[0];
