@@ -319,10 +319,12 @@ int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFea
   const int n = n_src * k;
   *n_matches = n;
   if (n <= 10) return LGICP_OK;  // IcpLoopComputation.cc:1002
-  if (n > 24576)
+  // the consistency graph is a dense n x n bit matrix: 65536 matches are 512 MiB of rows
+  constexpr int kMaxMatches = 65536;
+  if (n > kMaxMatches)
     return fail(ctx, LGICP_E_UNSUPPORTED,
-                "TEASER++ initialisation: %d descriptor matches exceed the 24576 the consistency "
-                "graph is sized for (raise harris_threshold or harris_radius)", n);
+                "TEASER++ initialisation: %d descriptor matches exceed the %d the consistency "
+                "graph is sized for (raise harris_threshold or harris_radius)", n, kMaxMatches);
   std::vector<double> s((size_t)3 * n), d((size_t)3 * n);
   for (int i = 0; i < n_src; ++i)
     for (int q = 0; q < k; ++q)

@@ -20,7 +20,7 @@ def main():
         st = [out[i].status for i in range(n_pairs)]
         print(json.dumps({"rep": rep, "wall_ms": 1e3 * dt, "ms_per_pair": 1e3 * dt / n_pairs,
                           "ok": sum(s == 0 for s in st), "rejected": sum(s == capi.PAIR_INIT_REJECTED for s in st),
-                          "total_ms": c.stats().total_ms}))
+                          "total_ms": c.stats().total_ms}), flush=True)
     c.close()
 
 main()
