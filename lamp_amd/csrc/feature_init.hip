@@ -200,6 +200,103 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __
   bits[gid] = m;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// GNC-TLS rotation over the pairwise differences of a clique of m matches (the host loop is
+// teaser::gnc_rotation): with m in the thousands the m (m - 1) / 2 differences are millions and
+// every one of the up to 100 iterations sums over all of them.  Workgroup (bx, i) owns the
+// differences (i, j), j = bx * 256 + lane, j > i, recomputed from the m points each time.  One
+// launch does everything an iteration needs from a given rotation: residuals, their maximum, the
+// cost under the old weights, the new weights (kept in an m x m array) and the correlation
+// matrix under the new weights for the next rotation.  Each workgroup leaves 11 partial values;
+// gnc_fold_kernel adds them in a fixed order.
+struct GncStep {
+  double R[9];
+  double th1, th2, c, mu;  // weight = 0 above th1, 1 below th2, sqrt(c / res) - mu between
+  int init;                // old weights are 1 (nothing stored yet)
+  int update;              // write the new weights and use them for the correlation
+};
+constexpr int GNC_THREADS = 256;
+constexpr int GNC_VALUES = 11;  // H (9), cost, max residual
+
+__global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __restrict__ cs,
+                                                               const double* __restrict__ cd,
+                                                               int m, GncStep k,
+                                                               double* __restrict__ w,
+                                                               double* __restrict__ partial) {
+  __shared__ double sh[GNC_THREADS / 64][GNC_VALUES];
+  const int i = blockIdx.y, j = blockIdx.x * GNC_THREADS + threadIdx.x;
+  double v[GNC_VALUES];
+#pragma unroll
+  for (int q = 0; q < GNC_VALUES; ++q) v[q] = 0.0;
+  if (j > i && j < m) {
+    double x[3], y[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) x[a] = cs[3 * j + a] - cs[3 * i + a], y[a] = cd[3 * j + a] - cd[3 * i + a];
+    double res = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double d = y[a] - (k.R[a * 3] * x[0] + k.R[a * 3 + 1] * x[1] + k.R[a * 3 + 2] * x[2]);
+      res += d * d;
+    }
+    const size_t o = (size_t)i * m + j;
+    const double wo = k.init ? 1.0 : w[o];
+    double wn = wo;
+    if (k.update) {
+      wn = res >= k.th1 ? 0.0 : (res <= k.th2 ? 1.0 : sqrt(k.c / res) - k.mu);
+      w[o] = wn;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) v[a * 3 + b] = x[a] * wn * y[b];
+    v[9] = wo * res;
+    v[10] = res;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < GNC_VALUES; ++q) {
+    double a = v[q];
+    for (int off = 32; off > 0; off >>= 1) {
+      const double b = __shfl_xor(a, off);
+      a = q == 10 ? fmax(a, b) : a + b;
+    }
+    if (lane == 0) sh[wave][q] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < GNC_VALUES) {
+    const int q = threadIdx.x;
+    double a = sh[0][q];
+    for (int wv = 1; wv < GNC_THREADS / 64; ++wv) a = q == 10 ? fmax(a, sh[wv][q]) : a + sh[wv][q];
+    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GNC_VALUES + q] = a;
+  }
+}
+
+// out[q] = fold of partial[0..n)[q]: lane t adds rows t, t + 256, ... in order, then the 256
+// lane sums are added in lane order
+__global__ __launch_bounds__(GNC_THREADS) void gnc_fold_kernel(const double* __restrict__ partial,
+                                                               int n, double* __restrict__ out) {
+  __shared__ double sh[GNC_THREADS][GNC_VALUES];
+  double v[GNC_VALUES];
+#pragma unroll
+  for (int q = 0; q < GNC_VALUES; ++q) v[q] = 0.0;
+  for (int r = threadIdx.x; r < n; r += GNC_THREADS)
+#pragma unroll
+    for (int q = 0; q < GNC_VALUES; ++q) {
+      const double b = partial[(size_t)r * GNC_VALUES + q];
+      v[q] = q == 10 ? fmax(v[q], b) : v[q] + b;
+    }
+#pragma unroll
+  for (int q = 0; q < GNC_VALUES; ++q) sh[threadIdx.x][q] = v[q];
+  __syncthreads();
+  if (threadIdx.x < GNC_VALUES) {
+    const int q = threadIdx.x;
+    double a = sh[0][q];
+    for (int t = 1; t < GNC_THREADS; ++t) a = q == 10 ? fmax(a, sh[t][q]) : a + sh[t][q];
+    out[q] = a;
+  }
+}
+
 }  // namespace lgicp
 
 namespace lgicp_detail {
@@ -302,14 +399,88 @@ static int feature_knn_table(lgicp_ctx* ctx, const CloudFeatures& src, const Clo
   return LGICP_OK;
 }
 
-// GetTeaserInitialAlignment from the keypoints on (IcpLoopComputation.cc:990-1081).  T_out is
-// the guess unless the TEASER++ transform scores at least as well over the matches.
-int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                        const float guess[16], float T_out[16], int* used, int* n_matches,
-                        int* n_clique) {
+// teaser::clique_rotation_host with the sums over the pairwise differences on the device.
+// Runs on a stream of its own: several pairs are solved at once from different host threads.
+// Returns false when the device refuses (the caller reports it).
+static bool clique_rotation_device(const std::vector<double>& cs, const std::vector<double>& cd,
+                                   const lgicp::teaser::Params& p, double R[9]) {
   namespace tz = lgicp::teaser;
-  std::memcpy(T_out, guess, sizeof(float) * 16);
-  *used = *n_matches = *n_clique = 0;
+  const int m = (int)(cs.size() / 3);
+  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+  bool ok = false;
+  {
+    Scratch dev;
+    const dim3 grid((m + lgicp::GNC_THREADS - 1) / lgicp::GNC_THREADS, m);
+    const int n_partial = (int)(grid.x * grid.y);
+    double* d_cs = dev.alloc<double>(cs.size());
+    double* d_cd = dev.alloc<double>(cd.size());
+    double* d_w = dev.alloc<double>((size_t)m * m);
+    double* d_partial = dev.alloc<double>((size_t)n_partial * lgicp::GNC_VALUES);
+    double* d_out = dev.alloc<double>(lgicp::GNC_VALUES);
+    double out[lgicp::GNC_VALUES];
+    auto step = [&](lgicp::GncStep k) -> bool {
+      hipLaunchKernelGGL(lgicp::gnc_step_kernel, grid, dim3(lgicp::GNC_THREADS), 0, st, d_cs, d_cd, m,
+                         k, d_w, d_partial);
+      hipLaunchKernelGGL(lgicp::gnc_fold_kernel, dim3(1), dim3(lgicp::GNC_THREADS), 0, st, d_partial,
+                         n_partial, d_out);
+      return hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    };
+    if (d_cs && d_cd && d_w && d_partial && d_out &&
+        hipMemcpyAsync(d_cs, cs.data(), sizeof(double) * cs.size(), hipMemcpyHostToDevice, st) == hipSuccess &&
+        hipMemcpyAsync(d_cd, cd.data(), sizeof(double) * cd.size(), hipMemcpyHostToDevice, st) == hipSuccess) {
+      ok = true;
+      double nb2 = p.noise_bound * p.noise_bound;
+      if (nb2 < 1e-16) nb2 = 1e-2;
+      lgicp::GncStep k{};
+      for (int i = 0; i < 9; ++i) k.R[i] = R[i];
+      k.init = 1;
+      // iteration 0 needs the largest residual under the unweighted rotation before it can
+      // set its weights: correlation of unit weights, then the residuals, then the update
+      ok = ok && step(k);
+      if (ok) {
+        tz::rotation_from_correlation(out, R);
+        for (int i = 0; i < 9; ++i) k.R[i] = R[i];
+        ok = step(k);
+      }
+      double mu = ok ? 1.0 / (2.0 * out[10] / nb2 - 1.0) : 0.0;
+      double prev_cost = INFINITY;
+      for (int it = 0; ok && mu > 0 && it < p.rotation_max_iterations; ++it) {
+        if (it > 0) {
+          tz::rotation_from_correlation(out, R);
+          for (int i = 0; i < 9; ++i) k.R[i] = R[i];
+          k.init = 0;
+        }
+        k.update = 1;
+        k.th1 = (mu + 1) / mu * nb2;
+        k.th2 = mu / (mu + 1) * nb2;
+        k.c = nb2 * mu * (mu + 1);
+        k.mu = mu;
+        ok = step(k);
+        const double cost = out[9];
+        const double cost_diff = std::fabs(cost - prev_cost);
+        mu *= p.rotation_gnc_factor;
+        prev_cost = cost;
+        if (cost_diff < p.rotation_cost_threshold) break;
+      }
+    }
+  }
+  (void)hipStreamDestroy(st);
+  return ok;
+}
+
+// GetTeaserInitialAlignment from the keypoints on (IcpLoopComputation.cc:990-1081), first half:
+// descriptor matches and their scale-consistency graph, both built on the device.
+int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
+                          TeaserJob* job) {
+  namespace tz = lgicp::teaser;
+  job->n_matches = 0;
+  job->src.clear();
+  job->dst.clear();
+  job->graph = tz::BitGraph();
   const int n_src = (int)src.idx.size(), n_tgt = (int)tgt.idx.size();
   if (n_src == 0 || n_tgt == 0) return LGICP_OK;
   const int k = std::min(5, n_tgt);  // calculateKCorrespondences(..., 5), IcpLoopComputation.cc:997
@@ -317,7 +488,7 @@ int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFea
   int rc = feature_knn_table(ctx, src, tgt, k, &nn);
   if (rc != LGICP_OK) return rc;
   const int n = n_src * k;
-  *n_matches = n;
+  job->n_matches = n;
   if (n <= 10) return LGICP_OK;  // IcpLoopComputation.cc:1002
   // the consistency graph is a dense n x n bit matrix: 65536 matches are 512 MiB of rows
   constexpr int kMaxMatches = 65536;
@@ -325,45 +496,72 @@ int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFea
     return fail(ctx, LGICP_E_UNSUPPORTED,
                 "TEASER++ initialisation: %d descriptor matches exceed the %d the consistency "
                 "graph is sized for (raise harris_threshold or harris_radius)", n, kMaxMatches);
-  std::vector<double> s((size_t)3 * n), d((size_t)3 * n);
+  std::vector<double>& s = job->src;
+  std::vector<double>& d = job->dst;
+  s.resize((size_t)3 * n);
+  d.resize((size_t)3 * n);
   for (int i = 0; i < n_src; ++i)
     for (int q = 0; q < k; ++q)
       for (int c = 0; c < 3; ++c) {
         s[3 * ((size_t)i * k + q) + c] = (double)src.xyz[3 * i + c];
         d[3 * ((size_t)i * k + q) + c] = (double)tgt.xyz[3 * nn[(size_t)i * k + q] + c];
       }
-  tz::Params prm;
-  tz::BitGraph g;
+  const tz::Params prm;
+  tz::BitGraph& g = job->graph;
   g.n = n;
   g.words = (n + 63) / 64;
   g.bits.resize((size_t)n * g.words);
-  {
-    hipStream_t st = ctx->stream;
-    Scratch dev;
-    double* d_s = dev.alloc<double>(s.size());
-    double* d_d = dev.alloc<double>(d.size());
-    unsigned long long* d_bits = dev.alloc<unsigned long long>(g.bits.size());
-    if (!d_s || !d_d || !d_bits) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
-    HIP_TRY(ctx, hipMemcpyAsync(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(d_d, d.data(), sizeof(double) * d.size(), hipMemcpyHostToDevice, st));
-    const long long total = (long long)n * g.words;
-    hipLaunchKernelGGL(lgicp::consistency_graph_kernel, dim3((unsigned)((total + 255) / 256)),
-                       dim3(256), 0, st, d_s, d_d, n, g.words,
-                       2.0 * prm.noise_bound * std::sqrt(prm.cbar2), d_bits);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(g.bits.data(), d_bits, sizeof(uint64_t) * g.bits.size(),
-                                hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-  }
-  const tz::Solution sol = tz::solve_on_clique(s, d, tz::greedy_clique(g), prm);
+  hipStream_t st = ctx->stream;
+  Scratch dev;
+  double* d_s = dev.alloc<double>(s.size());
+  double* d_d = dev.alloc<double>(d.size());
+  unsigned long long* d_bits = dev.alloc<unsigned long long>(g.bits.size());
+  if (!d_s || !d_d || !d_bits) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, hipMemcpyAsync(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_d, d.data(), sizeof(double) * d.size(), hipMemcpyHostToDevice, st));
+  const long long total = (long long)n * g.words;
+  hipLaunchKernelGGL(lgicp::consistency_graph_kernel, dim3((unsigned)((total + 255) / 256)),
+                     dim3(256), 0, st, d_s, d_d, n, g.words,
+                     2.0 * prm.noise_bound * std::sqrt(prm.cbar2), d_bits);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(g.bits.data(), d_bits, sizeof(uint64_t) * g.bits.size(),
+                              hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return LGICP_OK;
+}
+
+// Second half (safe to run for several pairs at once from different threads): clique, rotation,
+// translation and the acceptance test.  Graph work and 3x3 algebra stay on the host; the sums
+// over the clique's pairwise differences go to the device once the clique is large enough to
+// pay for the launches.  T_out is the guess unless the TEASER++ transform scores at least as
+// well over the matches.
+int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], float T_out[16],
+                  int* used, int* n_clique) {
+  namespace tz = lgicp::teaser;
+  std::memcpy(T_out, guess, sizeof(float) * 16);
+  *used = *n_clique = 0;
+  if (job.graph.n == 0) return LGICP_OK;
+  const tz::Params prm;
+  bool device_ok = true;
+  const tz::Solution sol = tz::solve_on_clique(
+      job.src, job.dst, tz::greedy_clique(job.graph), prm,
+      [&](const std::vector<double>& cs, const std::vector<double>& cd, const tz::Params& p, double R[9]) {
+        if (cs.size() / 3 < 128)
+          tz::clique_rotation_host(cs, cd, p, R);
+        else
+          device_ok = clique_rotation_device(cs, cd, p, R);
+      });
+  if (!device_ok)
+    return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: rotation search over a clique of %d matches "
+                "failed on the device (%s)", (int)sol.clique.size(), hipGetErrorString(hipGetLastError()));
   *n_clique = (int)sol.clique.size();
   double Ro[9], to[3];
   for (int a = 0; a < 3; ++a) {
     for (int b = 0; b < 3; ++b) Ro[a * 3 + b] = (double)guess[a * 4 + b];
     to[a] = (double)guess[a * 4 + 3];
   }
-  const double e_teaser = tz::error_metric(s, d, sol.R, sol.t, 100.0);
-  const double e_odom = tz::error_metric(s, d, Ro, to, 100.0);
+  const double e_teaser = tz::error_metric(job.src, job.dst, sol.R, sol.t, 100.0);
+  const double e_odom = tz::error_metric(job.src, job.dst, Ro, to, 100.0);
   if (e_teaser <= e_odom) {  // IcpLoopComputation.cc:1065-1068
     for (int i = 0; i < 16; ++i) T_out[i] = (i == 15) ? 1.f : 0.f;
     for (int a = 0; a < 3; ++a) {
@@ -373,6 +571,18 @@ int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFea
     *used = 1;
   }
   return LGICP_OK;
+}
+
+int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
+                        const float guess[16], float T_out[16], int* used, int* n_matches,
+                        int* n_clique) {
+  std::memcpy(T_out, guess, sizeof(float) * 16);
+  *used = *n_matches = *n_clique = 0;
+  TeaserJob job;
+  const int rc = teaser_prepare_device(ctx, src, tgt, &job);
+  *n_matches = job.n_matches;
+  if (rc != LGICP_OK) return rc;
+  return teaser_finish(ctx, job, guess, T_out, used, n_clique);
 }
 
 }  // namespace lgicp_detail

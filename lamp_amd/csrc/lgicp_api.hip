@@ -23,6 +23,10 @@
 #include "lgicp_device.h"
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <mutex>
 #include <limits>
 #include <thread>
 
@@ -645,21 +649,99 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
                                                 h_clouds[c].n, &feats[c]);
           if (rc != LGICP_OK) return rc;
         }
-    for (int p = 0; p < n_pairs; ++p) {
+    if (cfg.init_method == LGICP_INIT_TEASERPP) {
+      // IcpLoopComputation.cc:528-531: never rejects; keeps the odometry guess unless the
+      // TEASER++ transform explains the descriptor matches at least as well.  The matches and
+      // their consistency graph come from the device one pair after the other; clique and
+      // rotation search are host work and run for a window of pairs on as many threads.
+      // The cost of a pair grows with the square of its clique, so pairs are handed out one
+      // by one: this thread produces (device work), up to 16 workers consume; at most `window`
+      // graphs or 1 GiB of them wait or are being solved at any time.
+      const int window = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      const bool trace = std::getenv("LGICP_TRACE") != nullptr;  // diagnostics on stderr
+      struct Slot {
+        TeaserJob job;
+        int pair = -1;
+        size_t bytes = 0;
+      };
+      std::vector<Slot> slots((size_t)window);
+      std::vector<int> free_slots, ready;
+      for (int j = 0; j < window; ++j) free_slots.push_back(j);
+      std::mutex mu;
+      std::condition_variable cv;
+      size_t held_bytes = 0;
+      bool closed = false;
+      std::atomic<int> rc_finish{LGICP_OK};
+      auto worker = [&]() {
+        for (;;) {
+          int j;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || closed; });
+            if (ready.empty()) return;
+            j = ready.back();
+            ready.pop_back();
+          }
+          const int p = slots[j].pair;
+          const PairPlan& pp = bp.pairs[p];
+          float T0[16];
+          int used = 0, nc = 0;
+          const auto t_a = std::chrono::steady_clock::now();
+          const int rc = teaser_finish(ctx, slots[j].job, pp.guess, T0, &used, &nc);
+          if (rc != LGICP_OK) rc_finish.store(rc);
+          if (trace)
+            std::fprintf(stderr, "[lgicp] teaser pair %d: %d matches, clique %d, host %.1f ms\n", p,
+                         slots[j].job.n_matches, nc,
+                         1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count());
+          out[pp.cand].init_fitness = used ? (double)nc : 0.0;
+          std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
+          if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            held_bytes -= slots[j].bytes;
+            free_slots.push_back(j);
+          }
+          cv.notify_all();
+        }
+      };
+      std::vector<std::thread> pool;
+      for (int j = 0; j < window; ++j) pool.emplace_back(worker);
+      int rc_prepare = LGICP_OK;
+      for (int p = 0; p < n_pairs && rc_prepare == LGICP_OK; ++p) {
+        int j;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return !free_slots.empty() && held_bytes < (1ull << 30); });
+          j = free_slots.back();
+          free_slots.pop_back();
+        }
+        const PairPlan& pp = bp.pairs[p];
+        rc_prepare = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], &slots[j].job);
+        slots[j].pair = p;
+        slots[j].bytes = slots[j].job.graph.bits.size() * sizeof(uint64_t);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (rc_prepare == LGICP_OK) {
+            held_bytes += slots[j].bytes;
+            ready.push_back(j);
+          } else {
+            free_slots.push_back(j);
+          }
+        }
+        cv.notify_all();
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        closed = true;
+      }
+      cv.notify_all();
+      for (std::thread& t : pool) t.join();
+      if (rc_prepare != LGICP_OK) return rc_prepare;
+      if (rc_finish.load() != LGICP_OK) return rc_finish.load();
+    }
+    for (int p = 0; p < n_pairs && cfg.init_method == LGICP_INIT_FEATURES; ++p) {
       const PairPlan& pp = bp.pairs[p];
       float T0[16];
-      if (cfg.init_method == LGICP_INIT_TEASERPP) {
-        // IcpLoopComputation.cc:528-531: never rejects; keeps the odometry guess unless the
-        // TEASER++ transform explains the descriptor matches at least as well
-        int used = 0, nm = 0, nc = 0;
-        const int rc = teaser_align_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], pp.guess,
-                                           T0, &used, &nm, &nc);
-        if (rc != LGICP_OK) return rc;
-        out[pp.cand].init_fitness = used ? (double)nc : 0.0;
-        std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
-        if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
-        continue;
-      }
       double score = 0;
       // one fixed sampling sequence per (key_from, key_to): results do not depend on how the
       // candidates were batched

@@ -13,6 +13,7 @@
 #include "../../include/lamp_gicp.h"
 #include "host_math.h"
 #include "lgicp_device.h"
+#include "teaser.h"
 
 using namespace lgicp;
 
@@ -168,6 +169,17 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
 int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                         const float guess[16], float T_out[16], int* used, int* n_matches,
                         int* n_clique);
+// the same in two halves: the device half of one pair can run while the host halves of earlier
+// pairs are still being solved on other threads
+struct TeaserJob {
+  int n_matches = 0;
+  std::vector<double> src, dst;  // matched keypoints, [n_matches][3]
+  lgicp::teaser::BitGraph graph; // empty when there are too few matches to solve
+};
+int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
+                          TeaserJob* job);
+int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], float T_out[16],
+                  int* used, int* n_clique);
 
 inline int fail(lgicp_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];

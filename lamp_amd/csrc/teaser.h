@@ -86,6 +86,11 @@ inline std::vector<int> greedy_clique(const BitGraph& g) {
   std::vector<int> order(n);
   for (int i = 0; i < n; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return K[a] > K[b]; });
+  // candidates only ever leave the set, so the preferred one (largest bound, then largest id)
+  // is found by walking a list sorted that way instead of scanning the whole set every time
+  std::vector<int> pref(n);
+  for (int i = 0; i < n; ++i) pref[i] = i;
+  std::sort(pref.begin(), pref.end(), [&](int a, int b) { return K[a] != K[b] ? K[a] > K[b] : a > b; });
   int mc = 0;
   std::vector<uint64_t> cand(g.words);
   std::vector<int> C;
@@ -103,17 +108,9 @@ inline std::vector<int> greedy_clique(const BitGraph& g) {
     }
     if (np <= mc) continue;
     C.clear();
-    for (;;) {
-      int u = -1;
-      for (int w = 0; w < g.words; ++w) {
-        uint64_t m = cand[w];
-        while (m) {
-          const int x = (w << 6) + __builtin_ctzll(m);
-          m &= m - 1;
-          if (u < 0 || K[x] >= K[u]) u = x;  // ascending scan: the last maximum has the largest id
-        }
-      }
-      if (u < 0) break;
+    for (int at = 0; at < n; ++at) {
+      const int u = pref[at];
+      if (!((cand[u >> 6] >> (u & 63)) & 1)) continue;
       C.push_back(u);
       const uint64_t* r = g.row(u);
       for (int w = 0; w < g.words; ++w) cand[w] &= r[w];
@@ -203,6 +200,8 @@ inline double det3(const double M[9]) {
          M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
 
+inline void rotation_from_correlation(const double H[9], double R[9]);
+
 // weighted Kabsch without centring (the inputs are differences): R = V U^T of X diag(w) Y^T
 inline void weighted_rotation(const std::vector<double>& X, const std::vector<double>& Y,
                               const std::vector<double>& w, double R[9]) {
@@ -211,6 +210,11 @@ inline void weighted_rotation(const std::vector<double>& X, const std::vector<do
   for (size_t i = 0; i < n; ++i)
     for (int a = 0; a < 3; ++a)
       for (int b = 0; b < 3; ++b) H[a * 3 + b] += X[3 * i + a] * w[i] * Y[3 * i + b];
+  rotation_from_correlation(H, R);
+}
+
+// R = V U^T of H = X diag(w) Y^T, reflection removed
+inline void rotation_from_correlation(const double H[9], double R[9]) {
   double U[9], S[3], V[9];
   svd3(H, U, S, V);
   if (det3(U) * det3(V) < 0)
@@ -317,34 +321,53 @@ struct Solution {
   std::vector<int> clique;
 };
 
-// rotation and translation from the matches of the clique (src/dst are [n][3])
-inline Solution solve_on_clique(const std::vector<double>& src, const std::vector<double>& dst,
-                                std::vector<int> clique, const Params& p) {
-  Solution s;
-  s.clique = std::move(clique);
-  const int m = (int)s.clique.size();
-  if (m <= 1) return s;
+// rotation from the pairwise differences of the clique's matches (cs/cd are [m][3]), host version
+inline void clique_rotation_host(const std::vector<double>& cs, const std::vector<double>& cd,
+                                 const Params& p, double R[9]) {
+  const int m = (int)(cs.size() / 3);
   std::vector<double> st, dt;
   st.reserve((size_t)3 * m * (m - 1) / 2);
   dt.reserve((size_t)3 * m * (m - 1) / 2);
   for (int i = 0; i < m; ++i)
     for (int j = i + 1; j < m; ++j)
       for (int c = 0; c < 3; ++c) {
-        st.push_back(src[3 * s.clique[j] + c] - src[3 * s.clique[i] + c]);
-        dt.push_back(dst[3 * s.clique[j] + c] - dst[3 * s.clique[i] + c]);
+        st.push_back(cs[3 * j + c] - cs[3 * i + c]);
+        dt.push_back(cd[3 * j + c] - cd[3 * i + c]);
       }
-  gnc_rotation(st, dt, p, s.R);
+  gnc_rotation(st, dt, p, R);
+}
+
+// rotation and translation from the matches of the clique (src/dst are [n][3]); `rotation` is
+// clique_rotation_host or a drop-in that does the same sums elsewhere
+template <class RotationFn>
+inline Solution solve_on_clique(const std::vector<double>& src, const std::vector<double>& dst,
+                                std::vector<int> clique, const Params& p, RotationFn rotation) {
+  Solution s;
+  s.clique = std::move(clique);
+  const int m = (int)s.clique.size();
+  if (m <= 1) return s;
+  std::vector<double> cs((size_t)3 * m), cd((size_t)3 * m);
+  for (int i = 0; i < m; ++i)
+    for (int c = 0; c < 3; ++c) {
+      cs[3 * i + c] = src[3 * s.clique[i] + c];
+      cd[3 * i + c] = dst[3 * s.clique[i] + c];
+    }
+  rotation(cs, cd, p, s.R);
   std::vector<double> v(m);
   for (int a = 0; a < 3; ++a) {
     for (int i = 0; i < m; ++i) {
-      const double* x = &src[3 * s.clique[i]];
-      v[i] = dst[3 * s.clique[i] + a] -
-             (s.R[a * 3] * x[0] + s.R[a * 3 + 1] * x[1] + s.R[a * 3 + 2] * x[2]);
+      const double* x = &cs[3 * i];
+      v[i] = cd[3 * i + a] - (s.R[a * 3] * x[0] + s.R[a * 3 + 1] * x[1] + s.R[a * 3 + 2] * x[2]);
     }
     s.t[a] = tls_scalar(v, p.cbar2 * p.noise_bound);
   }
   s.valid = true;
   return s;
+}
+
+inline Solution solve_on_clique(const std::vector<double>& src, const std::vector<double>& dst,
+                                std::vector<int> clique, const Params& p) {
+  return solve_on_clique(src, dst, std::move(clique), p, clique_rotation_host);
 }
 
 // sum over matches of min(|R s + t - d|^2 / threshold, 1)
