@@ -245,6 +245,22 @@ int lgicp_compute_normals(lgicp_ctx* ctx, const float* xyz, size_t n, int k, flo
 int lgicp_icp_observability(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
                             double eigenvalues[3]);
 
+/* pcl::VoxelGrid with a cubic leaf, all fields averaged — the filter inside
+ * LampPcldFilter::AdaptiveGridFilter (lamp_utils/src/LampPcldFilter.cc:46-50) and the
+ * evaluation driver's grid filters (loop_closure/src/eval_loop_computation_test.cc:151-154,
+ * 244-247).  One output point per occupied cell in ascending cell index: the float mean of its
+ * points and, when normals/out_normals are given, the normalised sum of their normals.
+ * Non-finite points are skipped.  When the grid would need more than INT_MAX cells the input
+ * comes back unchanged, as PCL does.  out_* hold up to n points; *n_out receives the count. */
+int lgicp_voxel_grid(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
+                     double leaf_size, float* out_xyz, float* out_normals, size_t* n_out);
+/* pcl::RandomSample (LampPcldFilter.cc:26-33, eval_loop_computation_test.cc:193-196,234-237):
+ * exactly min(n_keep, n) points, input order kept.  PCL seeds rand() with the wall clock; here
+ * the draw is a function of `seed` alone. */
+int lgicp_random_sample(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
+                        size_t n_keep, uint32_t seed, float* out_xyz, float* out_normals,
+                        size_t* n_out);
+
 /* IcpLoopComputation::GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081): the same
  * keypoint/descriptor front end, every source descriptor matched with its 5 nearest target
  * descriptors, TEASER++ (noise bound 0.5, GNC-TLS rotation, greedy max-clique inlier selection)

@@ -18,7 +18,8 @@ EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_
            "lgicp_submit", "lgicp_get_stats", "lgicp_nn_search", "lgicp_covariances_from_normals",
            "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh",
            "lgicp_harris_keypoints", "lgicp_sac_initial_alignment",
-           "lgicp_teaser_initial_alignment", "lgicp_compute_normals", "lgicp_icp_observability"]
+           "lgicp_teaser_initial_alignment", "lgicp_compute_normals", "lgicp_icp_observability",
+           "lgicp_voxel_grid", "lgicp_random_sample"]
 
 
 class Config(C.Structure):
@@ -119,6 +120,10 @@ def lib():
                                             C.c_void_p]
         L.lgicp_icp_observability.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                               C.c_void_p]
+        L.lgicp_voxel_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+        L.lgicp_random_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -306,6 +311,31 @@ class Context:
         ev = np.empty(3, np.float64)
         self._check(lib().lgicp_icp_observability(self._h, _ptr(x), _ptr(nn), len(x), _ptr(ev)))
         return ev
+
+    def voxel_grid(self, xyz, leaf_size, normals=None):
+        """pcl::VoxelGrid with a cubic leaf.  Returns xyz, or (xyz, normals) when normals are given."""
+        x = _f32(xyz).reshape(-1, 3)
+        nn = None if normals is None else _f32(normals).reshape(-1, 3)
+        out = np.empty((len(x), 3), np.float32)
+        out_n = None if nn is None else np.empty((len(x), 3), np.float32)
+        m = C.c_size_t(0)
+        self._check(lib().lgicp_voxel_grid(self._h, _ptr(x), None if nn is None else _ptr(nn), len(x),
+                                           C.c_double(leaf_size), _ptr(out),
+                                           None if out_n is None else _ptr(out_n), C.byref(m)))
+        return out[:m.value].copy() if nn is None else (out[:m.value].copy(), out_n[:m.value].copy())
+
+    def random_sample(self, xyz, n_keep, seed=0, normals=None):
+        """pcl::RandomSample: min(n_keep, n) points in input order, drawn from `seed`."""
+        x = _f32(xyz).reshape(-1, 3)
+        nn = None if normals is None else _f32(normals).reshape(-1, 3)
+        out = np.empty((len(x), 3), np.float32)
+        out_n = None if nn is None else np.empty((len(x), 3), np.float32)
+        m = C.c_size_t(0)
+        self._check(lib().lgicp_random_sample(self._h, _ptr(x), None if nn is None else _ptr(nn), len(x),
+                                              C.c_size_t(max(int(n_keep), 0)), C.c_uint32(seed & 0xFFFFFFFF),
+                                              _ptr(out), None if out_n is None else _ptr(out_n),
+                                              C.byref(m)))
+        return out[:m.value].copy() if nn is None else (out[:m.value].copy(), out_n[:m.value].copy())
 
     def compute_ap(self, query, ref_normals, corr, T, normalize=True):
         q, rn = _f32(query).reshape(-1, 3), _f32(ref_normals).reshape(-1, 3)

@@ -170,51 +170,53 @@ def write_test_data(path, d):
 
 
 # ------------------------------------------------------------------------------------- filters
-def voxel_grid(xyz, leaf):
-    """pcl::VoxelGrid with a cubic leaf: one centroid per occupied voxel, voxels in the order
-    of their linear index (x fastest).  Only the coordinates are kept: the evaluation
-    recomputes the normals afterwards."""
-    xyz = np.asarray(xyz, np.float32)
-    if len(xyz) == 0:
-        return xyz
-    inv = np.float32(1.0 / leaf)
-    ijk = np.floor(xyz * inv).astype(np.int64)
-    ijk -= ijk.min(0)
-    dims = ijk.max(0) + 1
-    lin = ijk[:, 0] + dims[0] * (ijk[:, 1] + dims[1] * ijk[:, 2])
-    order = np.argsort(lin, kind="stable")
-    lin_s = lin[order]
-    starts = np.flatnonzero(np.r_[True, lin_s[1:] != lin_s[:-1]])
-    counts = np.diff(np.r_[starts, len(lin_s)])
-    sums = np.add.reduceat(xyz[order].astype(np.float64), starts, axis=0)
-    return (sums / counts[:, None]).astype(np.float32)
-
-
-def random_sample(xyz, n_keep, seed=0):
-    """pcl::RandomSample: n_keep points, original order kept (seeded here; PCL seeds with
-    time() unless told otherwise)."""
-    n = len(xyz)
-    if n_keep >= n:
-        return xyz
-    rng = np.random.default_rng(seed)
-    keep = np.sort(rng.choice(n, size=max(int(n_keep), 0), replace=False))
-    return xyz[keep]
-
-
-def adaptive_filter(xyz, target, min_leaf, max_leaf, init_leaf=0.25):
-    """EvalIcpLoopCompute::AdaptiveFilter without the observability term
-    (eval_loop_computation_test.cc:133-174): the leaf size is steered until the voxel-grid output
-    is within 10 points of the target (at most 100 rounds)."""
+def adaptive_filter(ctx, xyz, normals, target, min_leaf, max_leaf, observability_check=False,
+                    init_leaf=0.25):
+    """EvalIcpLoopCompute::AdaptiveFilter (eval_loop_computation_test.cc:127-174): voxel-grid the
+    original cloud with a leaf size that is steered until the output is within 10 points of the
+    target (at most 100 rounds).  The grid and the observability run on the device."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
     if len(xyz) < target:
-        return xyz
-    leaf, out = init_leaf, xyz
+        return xyz, normals
+    leaf, out, out_n = init_leaf, xyz, normals
+    prev_obs = 0.0
+    if observability_check:
+        prev_obs = float(np.min(ctx.icp_observability(out, out_n))) / len(out)
     for _ in range(100):
         if abs(len(out) - target) <= 10:
             break
-        out = voxel_grid(xyz, leaf)
+        out, out_n = ctx.voxel_grid(xyz, leaf, normals)
+        obs_factor = 0.0
+        if observability_check:
+            obs = float(np.min(ctx.icp_observability(out, out_n))) / len(out)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                obs_factor = float((np.float64(prev_obs) - obs) / np.float64(prev_obs))
+            prev_obs = obs
         size_factor = len(out) / float(target)
-        leaf = min(max_leaf, max(min_leaf, leaf * size_factor))
-    return out
+        v = leaf * (size_factor - abs(size_factor - 1) * obs_factor)
+        m = v if min_leaf < v else min_leaf      # std::max(min_leaf, v), NaN included
+        leaf = m if m < max_leaf else max_leaf   # std::min(max_leaf, m)
+    return out, out_n
+
+
+def filter_keyed_scan(ctx, xyz, normals, filters, seed=0):
+    """EvalIcpLoopCompute::FilterKeyedScans up to the point where the normals are dropped
+    (eval_loop_computation_test.cc:211-250): adaptive grid, random sample, fixed grid."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    if normals is None:
+        normals = np.zeros_like(xyz)
+    if filters.get("adaptive_filter"):
+        xyz, normals = adaptive_filter(ctx, xyz, normals, filters.get("adaptive_target", 3000),
+                                       filters.get("adaptive_min_grid", 0.1),
+                                       filters.get("adaptive_max_grid", 0.8),
+                                       filters.get("observability_check", False))
+    if filters.get("random_filter"):
+        keep = int((1.0 - filters.get("decimate_percentage", 0.8)) * len(xyz))
+        xyz, normals = ctx.random_sample(xyz, keep, seed, normals)
+    if filters.get("grid_filter"):
+        xyz, normals = ctx.voxel_grid(xyz, filters.get("grid_res", 0.8), normals)
+    return xyz, normals
 
 
 # ------------------------------------------------------------------------------------- poses
@@ -262,16 +264,7 @@ def evaluate(data, use_gt_odom=False, filters=None, normals_k=10, **config):
     try:
         sizes = []
         for key, s in enumerate(data.scans):
-            xyz = s["xyz"]
-            if filters.get("adaptive_filter"):
-                xyz = adaptive_filter(xyz, filters.get("adaptive_target", 3000),
-                                      filters.get("adaptive_min_grid", 0.1),
-                                      filters.get("adaptive_max_grid", 0.8))
-            if filters.get("random_filter"):
-                keep = int((1.0 - filters.get("decimate_percentage", 0.8)) * len(xyz))
-                xyz = random_sample(xyz, keep, seed=key)
-            if filters.get("grid_filter"):
-                xyz = voxel_grid(xyz, filters.get("grid_res", 0.8))
+            xyz, _ = filter_keyed_scan(ctx, s["xyz"], s.get("normals"), filters, seed=key)
             # ConvertPointCloud + AddNormals: the stored normals are dropped and recomputed
             nrm, _ = ctx.compute_normals(xyz, normals_k) if len(xyz) else (np.zeros((0, 3)), None)
             ctx.add_keyframe(key, xyz, nrm)

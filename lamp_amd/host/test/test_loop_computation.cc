@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 
+#include "lamp_utils/LampPcldFilter.h"
 #include "loop_closure/GpuIcpLoopComputation.h"
 
 using namespace lamp_loop_closure;
@@ -221,10 +222,48 @@ static void OnDevice() {
   }
 }
 
+// LampPcldFilter (lamp_utils/src/LampPcldFilter.cc): leaf-size controller and filter chain on a
+// lattice whose cell counts are known in closed form
+static void PcldFilterOnDevice() {
+  lgicp_config cfg;
+  lgicp_default_config(&cfg, 1);
+  lgicp_ctx* ctx = nullptr;
+  CHECK(lgicp_create(&cfg, &ctx) == LGICP_OK);
+  if (!ctx) return;
+  PointCloud lattice;
+  for (int i = 0; i < 20; ++i)
+    for (int j = 0; j < 20; ++j)
+      for (int k = 0; k < 10; ++k) {
+        pose_graph_msgs::PointXYZINormal p;
+        p.x = 0.1f * i + 0.05f, p.y = 0.1f * j + 0.05f, p.z = 0.1f * k + 0.05f;
+        p.normal_z = 1.f;
+        lattice.push_back(p);
+      }
+  LampPcldFilterParams prm;
+  prm.adaptive_grid_target = 1000;
+  prm.decimate_percentage = 0.5;
+  LampPcldFilter filter(ctx, prm, 7);
+  CHECK(filter.grid_leaf_size() == 0.55);
+  PointCloud out;
+  CHECK(filter.Filter(lattice, &out));
+  CHECK(out.size() == 16);                 // 4 x 4 x 2 cells of 0.55 m, half of them kept
+  CHECK(filter.grid_leaf_size() == 0.1);   // 0.55 * 32 / 1000, clamped to the minimum
+  CHECK(filter.Filter(lattice, &out));
+  CHECK(out.size() == 2000);               // every lattice point has its own 0.1 m cell
+  CHECK(std::fabs(filter.grid_leaf_size() - 0.4) < 1e-12);
+  for (const auto& p : out) CHECK(p.normal_z == 1.f && p.normal_x == 0.f);
+  PointCloud few(lattice.begin(), lattice.begin() + 10), same;
+  prm.random_filter = false;
+  LampPcldFilter pass(ctx, prm);
+  CHECK(pass.Filter(few, &same) && same.size() == 10 && same[3].x == few[3].x);
+  lgicp_destroy(ctx);
+}
+
 int main(int argc, char** argv) {
   const bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
   HostOnly();
   if (!host_only) OnDevice();
+  if (!host_only) PcldFilterOnDevice();
   if (g_fail) {
     std::fprintf(stderr, "%d check(s) failed\n", g_fail);
     return 1;

@@ -155,6 +155,14 @@ void lo_compute_normals(const float* xyz, int n, int k, float* normals, float* c
 void lo_extract_normals(const float* xyz, const float* stored, int n, int k, float* normals,
                         int threads);
 
+/* ------------------------------------------------------------------ down-sampling filters */
+/* pcl::VoxelGrid, cubic leaf, all fields (LampPcldFilter.cc:46-50); returns the output count.
+ * normals / out_normals may be NULL.  out_* hold up to n points. */
+size_t lo_voxel_grid(const float* xyz, const float* normals, size_t n, double leaf_size,
+                     float* out_xyz, float* out_normals);
+/* pcl::RandomSample's contract (LampPcldFilter.cc:26-33) with a seeded draw; ascending indices */
+size_t lo_random_sample(size_t n, size_t n_keep, uint32_t seed, int32_t* out_indices);
+
 /* ------------------------------------------------------------------ TEASER++ (parity unpinned) */
 /* GetTeaserInitialAlignment (IcpLoopComputation.cc:949-1081) from the keypoints on; see
  * lo_teaser.c for the restated algorithm.  pairs is [count][2] = (source, target) keypoint ids */

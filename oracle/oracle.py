@@ -343,6 +343,65 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def voxel_grid(xyz, leaf_size, normals=None):
+    """pcl::VoxelGrid, cubic leaf.  Returns xyz, or (xyz, normals) when normals are given."""
+    x = _f32(xyz).reshape(-1, 3)
+    nn = None if normals is None else _f32(normals).reshape(-1, 3)
+    out = np.empty((len(x), 3), np.float32)
+    out_n = None if nn is None else np.empty((len(x), 3), np.float32)
+    f = lib().lo_voxel_grid
+    f.restype = C.c_size_t
+    m = f(_p(x, C.c_float), None if nn is None else _p(nn, C.c_float), C.c_size_t(len(x)),
+          C.c_double(leaf_size), _p(out, C.c_float), None if out_n is None else _p(out_n, C.c_float))
+    return out[:m].copy() if nn is None else (out[:m].copy(), out_n[:m].copy())
+
+
+def random_sample_indices(n, n_keep, seed=0):
+    idx = np.empty(max(n, 1), np.int32)
+    f = lib().lo_random_sample
+    f.restype = C.c_size_t
+    m = f(C.c_size_t(n), C.c_size_t(max(int(n_keep), 0)), C.c_uint32(seed & 0xFFFFFFFF), _p(idx, C.c_int32))
+    return idx[:m].copy()
+
+
+class LampPcldFilterOracle:
+    """LampPcldFilter (lamp_utils/src/LampPcldFilter.cc:12-72) on the CPU restatements; params is
+    any object with the reference's field names."""
+
+    def __init__(self, params, seed=0):
+        self.p = params
+        self.leaf = (params.adaptive_max_grid + params.adaptive_min_grid) / 2.0
+        self.prev_obs = 0.0
+        self.seed, self.count = seed, 0
+
+    def filter(self, xyz, normals):
+        xyz, normals = self.adaptive_grid_filter(xyz, normals)
+        if self.p.random_filter:
+            keep = random_sample_indices(len(xyz), int((1.0 - self.p.decimate_percentage) * len(xyz)),
+                                         self.seed + self.count)
+            xyz, normals = xyz[keep], normals[keep]
+        self.count += 1
+        return xyz, normals
+
+    def adaptive_grid_filter(self, xyz, normals):
+        p = self.p
+        xyz, normals = _f32(xyz).reshape(-1, 3), _f32(normals).reshape(-1, 3)
+        if len(xyz) < p.adaptive_grid_target:
+            return xyz, normals
+        xyz, normals = voxel_grid(xyz, self.leaf, normals)
+        size_factor = len(xyz) / float(p.adaptive_grid_target)
+        obs_factor = 0.0
+        if p.observability_check:
+            obs = float(np.min(icp_observability(xyz, normals))) / float(len(xyz))
+            self.prev_obs = obs                      # the first-cloud flag is never set
+            with np.errstate(divide="ignore", invalid="ignore"):
+                obs_factor = float((np.float64(self.prev_obs) - obs) / np.float64(self.prev_obs))
+        v = self.leaf * (size_factor - abs(size_factor - 1) * obs_factor)
+        m = v if p.adaptive_min_grid < v else p.adaptive_min_grid
+        self.leaf = m if m < p.adaptive_max_grid else p.adaptive_max_grid
+        return xyz, normals
+
+
 def teaser_matches(src_feat, tgt_feat, k=5):
     sf, tf = _f32(src_feat), _f32(tgt_feat)
     pairs = np.empty((len(sf) * k, 2), np.int32)

@@ -79,27 +79,6 @@ def test_key_must_equal_line_number(tmp_path):
         D.load_test_data(str(tmp_path))
 
 
-def test_filters():
-    rng = np.random.default_rng(1)
-    xyz = rng.uniform(0, 4, size=(5000, 3)).astype(np.float32)
-    v = D.voxel_grid(xyz, 1.0)
-    assert len(v) == 64                                        # 4 x 4 x 4 occupied voxels
-    cells = np.floor(v).astype(int)
-    assert len({tuple(c) for c in cells}) == 64                # one centroid per voxel
-    lin = cells[:, 0] + 4 * (cells[:, 1] + 4 * cells[:, 2])
-    assert np.all(np.diff(lin) > 0)                            # in voxel-index order
-    assert np.allclose(v.mean(0), xyz.mean(0), atol=0.05)
-    s = D.random_sample(xyz, 1000, seed=3)
-    assert len(s) == 1000 and np.array_equal(s, D.random_sample(xyz, 1000, seed=3))
-    pos = {tuple(p): i for i, p in enumerate(xyz)}
-    assert np.all(np.diff([pos[tuple(p)] for p in s]) > 0)     # original order kept
-    # the reference's leaf-size controller is undamped (it may end on a clamp): only the
-    # clamps are guaranteed
-    a = D.adaptive_filter(xyz, 500, 0.1, 0.8)
-    assert len(D.voxel_grid(xyz, 0.8)) <= len(a) <= len(D.voxel_grid(xyz, 0.1))
-    assert D.adaptive_filter(xyz[:100], 500, 0.1, 0.8) is not None and len(D.adaptive_filter(xyz[:100], 500, 0.1, 0.8)) == 100
-
-
 def test_summary_formulas():
     """OutputTestSummary (TestUtils.cc:554-745): errors are the norms of the two halves of
     Logmap(edge.between(gt_from.between(gt_to))), degrees use 180/3.1416."""
@@ -138,6 +117,16 @@ def test_evaluate_synthetic_data_set(tmp_path):
         # neighbour scans are accumulated with the noisy odometry (5 cm, 1 deg): a few centimetres remain
         assert r["max-trans-error(m)"] < 0.15 and r["max-rot-error(deg)"] < 2.0
     assert info["min_ks_size"] == info["max_ks_size"] == 4096
+    # the same data set through the evaluation driver's filters (adaptive grid to a target size,
+    # random sample): every keyed scan shrinks, loops are still found
+    res2, fres2, info2 = D.evaluate(data, init_method=capi.INIT_ODOMETRY,
+                                    filters={"adaptive_filter": True, "adaptive_target": 2000,
+                                             "adaptive_min_grid": 0.05, "adaptive_max_grid": 0.8,
+                                             "random_filter": True, "decimate_percentage": 0.25})
+    # (the leaf-size controller is undamped and may stop on a clamp: only "smaller" is certain)
+    assert 0 < info2["min_ks_size"] <= info2["max_ks_size"] < 0.75 * 4096 + 1
+    assert len(res2) >= 0.75 * len(data.real_candidates) and len(fres2) == 0
+    print("filtered keyed-scan sizes", info2)
     head = open(tmp_path / "out" / "t_summary.csv").readline().strip()
     assert head.startswith("label,expected,detected,recall,false-positive-rate,mean-trans-error(m)")
     assert len(open(tmp_path / "out" / "t_fitness.csv").read().splitlines()) == 1 + len(res)
