@@ -61,10 +61,10 @@ struct CloudPlan {  // one distinct point cloud of a batch
 // 8 XCDs, so logical block (b % 8) * ceil(n/8) + b / 8 keeps neighbouring logical blocks (the
 // query tiles of one pair, which stream the same target) on one XCD's L2.
 template <typename T>
-void xcd_permute(std::vector<T>& v) {
+void xcd_permute(std::vector<T>& v, std::vector<T>& out) {
   const size_t n = v.size();
   if (n < 16) return;
-  std::vector<T> out(n);
+  out.resize(n);
   const size_t q = n / 8, r = n % 8;
   for (size_t b = 0; b < n; ++b) {
     const size_t x = b % 8, k = b / 8;
@@ -356,6 +356,14 @@ void guess_from_pose(const hm::Pose& p, bool with_translation, float g[16]) {
 // runs one device batch; results for bp.pairs[i] go to out[bp.pairs[i].cand]
 int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate* cand,
               lgicp_result* out) {
+  const bool trace_t = std::getenv("LGICP_TRACE") != nullptr;
+  const auto t_enter = std::chrono::steady_clock::now();
+  auto since = [&](const char* what) {
+    if (trace_t)
+      std::fprintf(stderr, "[lgicp] slot %d %s at %.3f ms\n", (int)(W - ctx->slot), what,
+                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
+  };
+
   const lgicp_config& cfg = ctx->cfg;
   hipStream_t st = W->stream;
   const int n_pairs = (int)bp.pairs.size();
@@ -467,8 +475,11 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     }
   }
 
-  std::vector<PairDev> h_pairs((size_t)n_pairs);
-  std::vector<PairState> h_state((size_t)n_pairs);
+  // the large host tables live in the slot: their pages stay mapped from batch to batch
+  std::vector<PairDev>& h_pairs = W->v_pairs;
+  std::vector<PairState>& h_state = W->v_state;
+  h_pairs.resize((size_t)n_pairs);
+  h_state.resize((size_t)n_pairs);
   int max_src_n = 0;
   for (int p = 0; p < n_pairs; ++p) {
     const PairPlan& pp = bp.pairs[p];
@@ -505,7 +516,8 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   // only, and when few are left their targets are split over several workgroups so that the
   // launch still offers >= ~4 workgroups per CU.
   const int QB = ctx->nn_exhaustive ? nn_queries_per_block(ctx->nn_variant) : NNP_THREADS;
-  std::vector<int4> h_bmap_nn, h_bmap_red;
+  std::vector<int4>& h_bmap_nn = W->v_bmap_nn;
+  std::vector<int4>& h_bmap_red = W->v_bmap_red;
   std::vector<int> h_ints((size_t)2 * n_pairs + 4, 0);
   bool any_split = false;
   auto build_maps = [&](const std::vector<int>& act) {
@@ -531,7 +543,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
         for (int s = 0; s < sp; ++s) h_bmap_nn.push_back(make_int4(p, t, s, sp));
       for (int c = 0; c < h_ints[p]; ++c) h_bmap_red.push_back(make_int4(p, c, h_ints[p], 0));
     }
-    xcd_permute(h_bmap_nn);
+    xcd_permute(h_bmap_nn, W->v_permute);
   };
   std::vector<int> all_pairs((size_t)n_pairs);
   size_t max_nn_blocks = 0;
@@ -539,7 +551,9 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   for (int p = 0; p < n_pairs; ++p) {
     all_pairs[p] = p;
     const PairDev& pd = h_pairs[p];
-    h_ints[p] = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + 4095) / 4096));
+    // slabs of 1024 source points (a function of the pair alone, so that its sums do not depend
+    // on the batch it travels in): short per-lane chains keep the stragglers' iterations short
+    h_ints[p] = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + 1023) / 1024));
     const int tiles = bp.clouds[bp.pairs[p].tgt_cloud].n_pad / NN_TILE;
     max_nn_blocks += (size_t)((pd.n_src + QB - 1) / QB) * (size_t)std::min(64, tiles);
     evals_per_pass += (double)pd.n_src * (double)pd.n_tgt;
@@ -613,6 +627,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   W->ev_used = 0;
   hipEvent_t ev_begin = W->event(), ev_prep = W->event();
   HIP_TRY(ctx, hipEventRecord(ev_begin, st));
+  since("tables uploaded");
 
   // ---- clouds: accumulate, pad, covariances, normalisation constants --------------------------
   HIP_TRY(ctx, launch_assemble(d_segs, (int)h_segs.size(), max_seg_n, st));
@@ -909,6 +924,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     }
   }
   HIP_TRY(ctx, hipStreamSynchronize(W->flag_stream));
+  since("loop done");
 
   // ---- final pass: fitness + correspondences + Ap ----------------------------------------------
   hipEvent_t ev_post0 = W->event(), ev_post1 = W->event(), ev_post2 = W->event();
@@ -921,16 +937,31 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
                                       !cfg.use_fixed_covariances,
                                   st));
   HIP_TRY(ctx, hipEventRecord(ev_post2, st));
-  std::vector<double> h_post((size_t)n_pairs * RED_MAX_CHUNKS * NPOST);
-  HIP_TRY(ctx, hipMemcpyAsync(h_post.data(), W->d_partials.p, sizeof(double) * h_post.size(),
+  // downloads land in pinned memory (a pageable destination makes every copy a staged,
+  // synchronous one)
+  const size_t post_bytes = sizeof(double) * (size_t)n_pairs * RED_MAX_CHUNKS * NPOST;
+  const size_t state_bytes = sizeof(PairState) * (size_t)n_pairs;
+  const size_t counter_bytes = sizeof(unsigned long long) * NN_COUNTER_SLOTS;
+  const size_t o_hstate = (post_bytes + 255) & ~(size_t)255;
+  const size_t o_hcount = (o_hstate + state_bytes + 255) & ~(size_t)255;
+  if (W->h_results_cap < o_hcount + counter_bytes) {
+    if (W->h_results) (void)hipHostFree(W->h_results);
+    W->h_results = nullptr, W->h_results_cap = 0;
+    const size_t want = (o_hcount + counter_bytes) * 5 / 4 + 4096;
+    HIP_TRY(ctx, hipHostMalloc((void**)&W->h_results, want, hipHostMallocDefault));
+    W->h_results_cap = want;
+  }
+  const double* const h_post = reinterpret_cast<const double*>(W->h_results);
+  const unsigned long long* const h_counters =
+      reinterpret_cast<const unsigned long long*>(W->h_results + o_hcount);
+  HIP_TRY(ctx, hipMemcpyAsync(W->h_results, W->d_partials.p, post_bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(W->h_results + o_hstate, d_state, state_bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(W->h_results + o_hcount, W->d_counters.p, counter_bytes,
                               hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(h_state.data(), d_state, sizeof(PairState) * n_pairs,
-                              hipMemcpyDeviceToHost, st));
-  std::vector<unsigned long long> h_counters(NN_COUNTER_SLOTS, 0);
-  HIP_TRY(ctx, hipMemcpyAsync(h_counters.data(), W->d_counters.p,
-                              sizeof(unsigned long long) * NN_COUNTER_SLOTS, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
-  for (unsigned long long v : h_counters) W->stats.nn_executed_evals += (double)v;
+  std::memcpy(h_state.data(), W->h_results + o_hstate, state_bytes);
+  since("results downloaded");
+  for (int k = 0; k < NN_COUNTER_SLOTS; ++k) W->stats.nn_executed_evals += (double)h_counters[k];
 
   // ---- timing ------------------------------------------------------------------------------
   auto sum_ms = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
@@ -1039,6 +1070,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     r.status = LGICP_PAIR_OK;
     S.pairs_ok++;
   }
+  since("batch done");
   return LGICP_OK;
 }
 
@@ -1106,7 +1138,36 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   const size_t max_pairs = std::min<size_t>(32767, (n_valid + ways - 1) / std::max(ways, 1));
   const size_t max_bytes = cfg.workspace_bytes / ways;
 
+  std::atomic<size_t> next{0};
+  std::atomic<int> rc_all{LGICP_OK};
+  std::mutex stats_mu;
+  double slot_total_ms[lgicp_ctx::MAX_SLOTS] = {0, 0, 0, 0};
   std::vector<BatchPlan> plans;
+  std::atomic<bool> plans_ready{false};
+  auto worker = [&](int si) {
+    // helpers are started before the plans exist, so that starting a thread overlaps the planning
+    while (!plans_ready.load(std::memory_order_acquire)) std::this_thread::yield();
+    if (hipSetDevice(cfg.device) != hipSuccess) {
+      rc_all = fail(ctx, LGICP_E_HIP, "hipSetDevice failed");
+      return;
+    }
+    BatchSlot* W = &ctx->slot[si];
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= plans.size() || rc_all != LGICP_OK) break;
+      std::memset(&W->stats, 0, sizeof(W->stats));
+      const int rc = run_batch(ctx, W, plans[k], cand, out);
+      std::lock_guard<std::mutex> lock(stats_mu);
+      merge_stats(ctx->stats, W->stats);
+      slot_total_ms[si] += W->stats.total_ms;
+      if (rc != LGICP_OK) {
+        rc_all = rc;
+        break;
+      }
+    }
+  };
+  std::vector<std::thread> others;
+  for (int k = 1; k < ways; ++k) others.emplace_back(worker, k);
   size_t i = 0;
   while (i < n) {
     BatchPlan bp;
@@ -1148,37 +1209,9 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
     if (!bp.pairs.empty()) plans.push_back(std::move(bp));
   }
 
-  std::atomic<size_t> next{0};
-  std::atomic<int> rc_all{LGICP_OK};
-  std::mutex stats_mu;
-  double slot_total_ms[lgicp_ctx::MAX_SLOTS] = {0, 0, 0, 0};
-  auto worker = [&](int si) {
-    if (hipSetDevice(cfg.device) != hipSuccess) {
-      rc_all = fail(ctx, LGICP_E_HIP, "hipSetDevice failed");
-      return;
-    }
-    BatchSlot* W = &ctx->slot[si];
-    for (;;) {
-      const size_t k = next.fetch_add(1);
-      if (k >= plans.size() || rc_all != LGICP_OK) break;
-      std::memset(&W->stats, 0, sizeof(W->stats));
-      const int rc = run_batch(ctx, W, plans[k], cand, out);
-      std::lock_guard<std::mutex> lock(stats_mu);
-      merge_stats(ctx->stats, W->stats);
-      slot_total_ms[si] += W->stats.total_ms;
-      if (rc != LGICP_OK) {
-        rc_all = rc;
-        break;
-      }
-    }
-  };
-  {
-    const int n_workers = (int)std::min<size_t>((size_t)ways, plans.size());
-    std::vector<std::thread> others;
-    for (int k = 1; k < n_workers; ++k) others.emplace_back(worker, k);
-    worker(0);
-    for (auto& t : others) t.join();
-  }
+  plans_ready.store(true, std::memory_order_release);
+  worker(0);
+  for (auto& t : others) t.join();
   // device span of the submit: the slots overlap
   ctx->stats.total_ms = *std::max_element(slot_total_ms, slot_total_ms + lgicp_ctx::MAX_SLOTS);
   return rc_all;

@@ -96,6 +96,12 @@ struct BatchSlot {
   DevBuf<double> d_partials;
   DevBuf<unsigned long long> d_counters;
   int* h_done = nullptr;  // pinned, 2 x 32768
+  char* h_results = nullptr;  // pinned landing area of a batch's downloads (partials, states, counters)
+  size_t h_results_cap = 0;
+  // host tables of the batch in flight (kept between batches: no page faults on reuse)
+  std::vector<lgicp::PairDev> v_pairs;
+  std::vector<lgicp::PairState> v_state;
+  std::vector<int4> v_bmap_nn, v_bmap_red, v_permute;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   lgicp_stats stats;  // what the batch in this slot adds to the context's statistics
@@ -125,6 +131,8 @@ struct BatchSlot {
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     ev_pool.clear();
     if (h_done) (void)hipHostFree(h_done);
+    if (h_results) (void)hipHostFree(h_results);
+    h_results = nullptr, h_results_cap = 0;
     if (flag_stream) (void)hipStreamDestroy(flag_stream);
     if (stream) (void)hipStreamDestroy(stream);
     h_done = nullptr, stream = flag_stream = nullptr;
