@@ -107,6 +107,47 @@ def test_filter_state_machine_oracle():
     assert g.leaf == 0.1
 
 
+class _CheckerEngine:
+    """Stands in for the engine context so that the host-side state machine of
+    lamp_amd.pcld_filter can be exercised without a GPU: same three calls, answered by the CPU
+    restatement."""
+
+    def voxel_grid(self, xyz, leaf, normals=None):
+        return O.voxel_grid(xyz, leaf, normals)
+
+    def random_sample(self, xyz, n_keep, seed=0, normals=None):
+        idx = O.random_sample_indices(len(xyz), n_keep, seed)
+        return (xyz[idx], normals[idx]) if normals is not None else xyz[idx]
+
+    def icp_observability(self, xyz, normals):
+        return O.icp_observability(xyz, normals)
+
+
+@pytest.mark.parametrize("observability", [False, True])
+def test_product_filter_host_logic(observability):
+    """lamp_amd.pcld_filter.LampPcldFilter (the host mirror the product ships) drives its engine
+    exactly as the restated reference class drives PCL: same outputs, same leaf size after
+    every scan, pass-through below the target, NaN observability falling to the lower clamp."""
+    p = LampPcldFilterParams(random_filter=True, decimate_percentage=0.7, adaptive_grid_target=800,
+                             adaptive_min_grid=0.1, adaptive_max_grid=1.5,
+                             observability_check=observability)
+    dev, ref = LampPcldFilter(_CheckerEngine(), p, seed=5), O.LampPcldFilterOracle(p, seed=5)
+    assert dev.grid_leaf_size == ref.leaf == 0.8
+    for k in range(4):
+        scan, sn = F.random_room_scan(9000, 30 + k)
+        x, n = dev.filter(scan, sn)
+        rx, rn = ref.filter(scan, sn)
+        assert np.array_equal(x, rx) and np.array_equal(n, rn) and dev.grid_leaf_size == ref.leaf
+    few, fn = _cloud(100, 9)
+    x, n = dev.filter(few, fn)
+    assert len(x) == int(0.3 * 100) and dev.grid_leaf_size == ref.leaf
+    if observability:
+        plane, pn = F.generate_plane()
+        flat = np.tile(plane, (9, 1)) + np.random.default_rng(1).normal(scale=1e-3, size=(900, 3)).astype(np.float32)
+        dev.adaptive_grid_filter(flat, np.tile(pn, (9, 1)))
+        assert dev.grid_leaf_size == 0.1
+
+
 # ----------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,leaf,seed", [(20000, 0.5, 0), (65536, 0.25, 1), (3000, 3.0, 2), (1, 1.0, 3)])

@@ -463,6 +463,23 @@ def test_teaser_initial_alignment_matches_oracle(seed, radius):
         c.close()
 
 
+def test_teaser_large_clique_matches_oracle():
+    """From 128 clique members on, the GNC-TLS sums over the clique's pairwise differences run on
+    the device (gnc_step_kernel) instead of the host loop the small cases take."""
+    from lamp_amd import capi
+    radius = 0.15
+    c = capi.Context(harris_radius=radius)
+    try:
+        src, sn, tgt, tn, _ = F.make_pair(12000, 47, rot_deg=4.0, trans=0.4)
+        T_ref, used_ref, nm_ref, nc_ref = O.teaser_initial_alignment(src, sn, tgt, tn, harris_radius=radius)
+        T, used, nm, nc = c.teaser_initial_alignment(src, sn, tgt, tn, None)
+        assert nc >= 128, nc
+        assert nm == nm_ref and nc == nc_ref and used == used_ref
+        assert np.allclose(T, T_ref, atol=1e-6)
+    finally:
+        c.close()
+
+
 def test_submit_teaser_init_matches_oracle():
     from lamp_amd import capi
     radius = 0.3
