@@ -96,7 +96,7 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     from lamp_amd import capi
-    from lamp_amd.sharding import gather_records, pack_results
+    from lamp_amd.sharding import RecordGatherer, pack_results
     from lamp_amd.workload import Workload
 
     work = Workload(args.config, pairs=args.pairs, points=args.points, keyframes=args.keyframes,
@@ -111,6 +111,11 @@ def main():
     cands = work.candidates()
     packed = ctx.pack_candidates(cands)     # the lgicp_candidate array a C++ caller hands over
 
+    gatherer = None
+    if dist is not None:
+        import torch
+        gatherer = RecordGatherer(dist, rank, world, len(cands), torch.device("cuda", local_rank))
+
     def barrier():
         if dist is not None:
             import torch
@@ -121,8 +126,7 @@ def main():
         out = ctx.submit_packed(packed)     # blocking: returns after the device work is done
         if dist is not None:
             import torch
-            gather_records(pack_results(out, len(cands)), dist, rank, world,
-                           torch.device("cuda", local_rank), equal_counts=True)
+            gatherer.gather(pack_results(out, len(cands)))   # rank 0 ends with every rank's records
             torch.cuda.synchronize()
         return out
 

@@ -92,3 +92,36 @@ def gather_records(records, dist, rank, world, device=None, equal_counts=False):
         return None
     parts = [gathered[r][: int(counts[r].item())].cpu().numpy() for r in range(world)]
     return np.concatenate(parts, axis=0)
+
+
+class RecordGatherer:
+    """The same gather for a loop that sends the same number of records every time: staging
+    buffers (pinned host, device, rank 0's landing area) are allocated once, the per-rank
+    parts arrive in one contiguous device tensor and reach the host in a single copy."""
+
+    def __init__(self, dist, rank, world, n_records, device):
+        import torch
+        self.dist, self.rank, self.world, self.n = dist, rank, world, n_records
+        pin = device.type == "cuda"
+        self.h_in = torch.zeros((n_records, RESULT_WIDTH), dtype=torch.float64, pin_memory=pin)
+        self.d_in = torch.zeros((n_records, RESULT_WIDTH), dtype=torch.float64, device=device)
+        self.d_all = self.h_all = None
+        if rank == 0:
+            self.d_all = torch.zeros((world, n_records, RESULT_WIDTH), dtype=torch.float64, device=device)
+            self.h_all = torch.zeros((world, n_records, RESULT_WIDTH), dtype=torch.float64, pin_memory=pin)
+
+    def gather(self, records):
+        """records: [n_records, RESULT_WIDTH] float64.  Returns [world * n_records, RESULT_WIDTH]
+        on rank 0 (a view of the landing buffer, valid until the next call), None elsewhere."""
+        import torch
+        if records.shape != (self.n, RESULT_WIDTH):
+            raise ValueError(f"expected {(self.n, RESULT_WIDTH)} records, got {records.shape}")
+        np.copyto(self.h_in.numpy(), records)
+        self.d_in.copy_(self.h_in, non_blocking=True)
+        self.dist.gather(self.d_in, list(self.d_all.unbind(0)) if self.rank == 0 else None, dst=0)
+        if self.rank != 0:
+            return None
+        self.h_all.copy_(self.d_all, non_blocking=True)
+        if self.d_all.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return self.h_all.numpy().reshape(self.world * self.n, RESULT_WIDTH)

@@ -54,6 +54,17 @@ def _worker(rank, world, port, out_path):
     rec = gather_records(pack_results(results), dist, rank, world)
     if rank == 0:
         np.save(out_path, rec)
+    # the fixed-count gatherer the benchmark uses: same buffers on every call
+    import torch
+    from lamp_amd.sharding import RESULT_WIDTH, RecordGatherer
+    g = RecordGatherer(dist, rank, world, 3, torch.device("cpu"))
+    for call in range(2):
+        mine3 = np.full((3, RESULT_WIDTH), 100.0 * call + 10.0 * rank) + np.arange(3)[:, None]
+        allr = g.gather(mine3)
+        if rank == 0:
+            np.save(out_path + f".fixed{call}.npy", allr.copy())
+        else:
+            assert allr is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,3 +82,7 @@ def test_two_rank_gloo_gather(tmp_path):
     got = sorted((int(r[0]), int(r[1])) for r in rec)
     assert got == sorted(work.pairs)
     assert np.all(rec[:, 2] == 0) and np.all(rec[:, 4] > 0)
+    for call in range(2):
+        fixed = np.load(out + f".fixed{call}.npy")
+        assert fixed.shape == (6, 128)
+        assert fixed[:, 0].tolist() == [100.0 * call + 10.0 * r + k for r in range(2) for k in range(3)]
