@@ -106,7 +106,10 @@ typedef struct lgicp_config {
   int reserved[8];            /* tuning/diagnostics, 0 = default: [0] queries per lane of the
                                  exhaustive 1-NN kernel (2, 4, 8); [1] its target splits;
                                  [2] 1 = use the exhaustive 1-NN kernel instead of the pruned
-                                 one; [3] first-round radius of the pruned search in mm */
+                                 one; [3] first-round radius of the pruned search in mm;
+                                 [5] 1 = host round trip after every outer iteration; [6] 1 = no
+                                 seeding of a lookup with the previous match; [7] parts of a
+                                 submit in flight at once (1..4, default 4) */
 } lgicp_config;
 
 /* pose_graph_msgs/LoopCandidate (pose_graph_msgs/msg/LoopCandidate.msg:1-18) */

@@ -542,8 +542,9 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     mat4f_mul(Tprev, G, Tf);  // final_transformation_ = previous_ * guess (gicp.hpp:583)
     for (int i = 0; i < 16; ++i) S.Tfinal[i] = Tf[i];
     S.active = 0;
-    n_done[1 + pair] = 1;  // per-pair "left the loop" flag, read by the host with the counter
-    atomicAdd(n_done, 1);
+    // per-pair "left the loop" flag; n_done lives in pinned host memory, the store becomes
+    // visible to the host at the latest when the kernel ends
+    n_done[1 + pair] = 1;
   }
 }
 

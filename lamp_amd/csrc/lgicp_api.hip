@@ -789,7 +789,13 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   sp.tf_epsilon = cfg.tf_epsilon;
   sp.max_iterations = cfg.iterations;
   sp.max_inner_iterations = cfg.optimizer_iterations;
-  int* d_done = d_ints + off_done;
+  // "Left the loop" flags, one per pair, raised by the solve kernel straight in pinned host memory
+  // (entry 0 is unused): no copy and no second stream between the device and the host's view
+  int* const h_live = W->h_done;
+  std::memset(h_live, 0, sizeof(int) * ((size_t)n_pairs + 1));
+  int* d_done = nullptr;
+  HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_done, h_live, 0));
+  (void)off_done;
   // One 1-NN pass over the pairs of the current block map.  Inside the GICP loop only matches
   // closer than the correspondence threshold are used (gicp.hpp:476), so the pruned search is
   // capped just above it; the pass after the loop is exact for every point.
@@ -854,8 +860,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   // "done" flags of iteration i are looked at, so the device never waits for the round trip.
   // Pairs that have left the loop are skipped by the kernels themselves (PairState::active);
   // the block maps only follow, two iterations late, to keep the grids small.
-  hipEvent_t flag_ev[2] = {W->event(), W->event()};
-  int* h_flags2[2] = {W->h_done, W->h_done + 32768};
+  hipEvent_t flag_ev[2] = {nullptr, nullptr};  // end of the solve kernel of an iteration
   auto enqueue_iteration = [&](int slot) -> int {
     hipEvent_t a = W->event(), b = W->event(), c = W->event(), d = W->event();
     HIP_TRY(ctx, hipEventRecord(a, st));
@@ -868,12 +873,9 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     HIP_TRY(ctx, launch_gicp_solve(d_pairs, d_state, n_pairs, d_ints,
                                    W->d_partials.p, sp, d_done, st));
     HIP_TRY(ctx, hipEventRecord(d, st));
-    // the flags travel on their own stream: the next iteration does not queue up behind the copy
-    // (a copy that overlaps the next solve kernel can only see more pairs done, never fewer)
-    HIP_TRY(ctx, hipStreamWaitEvent(W->flag_stream, d, 0));
-    HIP_TRY(ctx, hipMemcpyAsync(h_flags2[slot], d_done, sizeof(int) * ((size_t)n_pairs + 1),
-                                hipMemcpyDeviceToHost, W->flag_stream));
-    HIP_TRY(ctx, hipEventRecord(flag_ev[slot], W->flag_stream));
+    // once this event has passed, every flag of this iteration is visible to the host (a
+    // later solve kernel that is already running can only add flags, never take one back)
+    flag_ev[slot] = d;
     nn_ev.emplace_back(a, b);
     red_ev.emplace_back(b, c);
     sol_ev.emplace_back(c, d);
@@ -894,15 +896,17 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
         enqueued = true;
       }
       HIP_TRY(ctx, hipEventSynchronize(flag_ev[prev]));
-      const int* flags = h_flags2[prev];
-      const bool all_done = flags[0] >= n_active0;
+      const volatile int* flags = h_live;
+      int n_flagged = 0;
+      for (int p = 0; p < n_pairs; ++p) n_flagged += flags[1 + p] != 0;
+      const bool all_done = n_flagged >= n_active0;
       if (enqueued) ++outer;
       if (all_done || outer >= cfg.iterations + 1) {
         if (enqueued) HIP_TRY(ctx, hipStreamSynchronize(st));  // kernels found nothing to do
         break;
       }
-      if (flags[0] != done_seen) {
-        done_seen = flags[0];
+      if (n_flagged != done_seen) {
+        done_seen = n_flagged;
         active.clear();
         for (int p = 0; p < n_pairs; ++p)
           if (h_state[p].active && !flags[1 + p]) active.push_back(p);
@@ -923,7 +927,6 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
       }
     }
   }
-  HIP_TRY(ctx, hipStreamSynchronize(W->flag_stream));
   since("loop done");
 
   // ---- final pass: fitness + correspondences + Ap ----------------------------------------------

@@ -85,7 +85,6 @@ using namespace lgicp_detail;
 // bookkeeping) the other half's bulk kernels keep the GPU busy.
 struct BatchSlot {
   hipStream_t stream = nullptr;
-  hipStream_t flag_stream = nullptr;  // carries the "done" flags back to the host
   DevBuf<char> arena;                 // per-batch scratch (bump allocated)
   // clouds, pairs, states, segments, chunk counts + done flags, block maps: one buffer, one copy
   DevBuf<char> d_params;
@@ -95,7 +94,7 @@ struct BatchSlot {
   size_t h_maps_cap[2] = {0, 0};
   DevBuf<double> d_partials;
   DevBuf<unsigned long long> d_counters;
-  int* h_done = nullptr;  // pinned, 2 x 32768
+  int* h_done = nullptr;  // pinned and device-visible: the solve kernel raises per-pair "done" flags here
   char* h_results = nullptr;  // pinned landing area of a batch's downloads (partials, states, counters)
   size_t h_results_cap = 0;
   // host tables of the batch in flight (kept between batches: no page faults on reuse)
@@ -116,12 +115,10 @@ struct BatchSlot {
   }
   bool create() {
     return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
-           hipStreamCreateWithFlags(&flag_stream, hipStreamNonBlocking) == hipSuccess &&
            hipHostMalloc((void**)&h_done, sizeof(int) * 65536, hipHostMallocDefault) == hipSuccess;
   }
   void destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
-    if (flag_stream) (void)hipStreamSynchronize(flag_stream);
     arena.release(), d_params.release(), d_partials.release(), d_counters.release();
     if (h_params) (void)hipHostFree(h_params);
     for (int k = 0; k < 2; ++k)
@@ -133,9 +130,8 @@ struct BatchSlot {
     if (h_done) (void)hipHostFree(h_done);
     if (h_results) (void)hipHostFree(h_results);
     h_results = nullptr, h_results_cap = 0;
-    if (flag_stream) (void)hipStreamDestroy(flag_stream);
     if (stream) (void)hipStreamDestroy(stream);
-    h_done = nullptr, stream = flag_stream = nullptr;
+    h_done = nullptr, stream = nullptr;
   }
 };
 
@@ -151,7 +147,9 @@ struct lgicp_ctx {
   float nn_r0sq = 1.0f / 64.0f;  // squared radius of the pruned search's first round
   static constexpr int MAX_SLOTS = 4;
   BatchSlot slot[MAX_SLOTS];
-  int n_slots = 2;  // halves (or quarters) of a submit in flight at once; reserved[7] overrides
+  // parts of a submit in flight at once, one stream each (the GPU exposes 4 hardware queues
+  // per process); reserved[7] overrides
+  int n_slots = 4;
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
   DevBuf<IndexSegDev> d_isegs;   // for keyframe registration
   DevBuf<CloudDev> d_reg_cloud;
