@@ -68,13 +68,14 @@ def cpu_baseline(work, n_sample, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--pairs", type=int, default=None)
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--keyframes", type=int, default=None)
-    ap.add_argument("--cpu-sample", type=int, default=32)
+    ap.add_argument("--cpu-sample", type=int, default=256,
+                    help="pairs of the same workload timed on the host CPU (about 20 CPU-seconds on C2)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--nn-variant", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
