@@ -210,12 +210,14 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
     return fail(nullptr, LGICP_E_HIP, "stream / pinned allocation failed");
   }
   ctx->stream = ctx->slot[0].stream;
+  ctx->helpers.start(ctx->n_slots - 1);
   *out = ctx;
   return LGICP_OK;
 }
 
 void lgicp_destroy(lgicp_ctx* ctx) {
   if (!ctx) return;
+  ctx->helpers.shutdown();
   (void)hipSetDevice(ctx->cfg.device);
   for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
   for (auto& kv : ctx->scans) kv.second.free_device();
@@ -1141,23 +1143,22 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   const size_t max_pairs = std::min<size_t>(32767, (n_valid + ways - 1) / std::max(ways, 1));
   const size_t max_bytes = cfg.workspace_bytes / ways;
 
-  std::atomic<size_t> next{0};
   std::atomic<int> rc_all{LGICP_OK};
   std::mutex stats_mu;
   double slot_total_ms[lgicp_ctx::MAX_SLOTS] = {0, 0, 0, 0};
   std::vector<BatchPlan> plans;
   std::atomic<bool> plans_ready{false};
   auto worker = [&](int si) {
-    // helpers are started before the plans exist, so that starting a thread overlaps the planning
+    // helpers are woken before the plans exist, so that the wake-up overlaps the planning
     while (!plans_ready.load(std::memory_order_acquire)) std::this_thread::yield();
     if (hipSetDevice(cfg.device) != hipSuccess) {
       rc_all = fail(ctx, LGICP_E_HIP, "hipSetDevice failed");
       return;
     }
     BatchSlot* W = &ctx->slot[si];
-    for (;;) {
-      const size_t k = next.fetch_add(1);
-      if (k >= plans.size() || rc_all != LGICP_OK) break;
+    // part k of a submit always runs in slot k mod ways: repeated submits of the same shape find
+    // every slot's buffers already sized for their part
+    for (size_t k = (size_t)si; k < plans.size() && rc_all == LGICP_OK; k += (size_t)ways) {
       std::memset(&W->stats, 0, sizeof(W->stats));
       const int rc = run_batch(ctx, W, plans[k], cand, out);
       std::lock_guard<std::mutex> lock(stats_mu);
@@ -1169,8 +1170,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
       }
     }
   };
-  std::vector<std::thread> others;
-  for (int k = 1; k < ways; ++k) others.emplace_back(worker, k);
+  ctx->helpers.post(ways - 1, worker);
   size_t i = 0;
   while (i < n) {
     BatchPlan bp;
@@ -1214,7 +1214,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
 
   plans_ready.store(true, std::memory_order_release);
   worker(0);
-  for (auto& t : others) t.join();
+  ctx->helpers.wait();
   // device span of the submit: the slots overlap
   ctx->stats.total_ms = *std::max_element(slot_total_ms, slot_total_ms + lgicp_ctx::MAX_SLOTS);
   return rc_all;

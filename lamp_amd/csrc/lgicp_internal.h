@@ -3,9 +3,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -135,6 +139,67 @@ struct BatchSlot {
   }
 };
 
+// Helper threads of a context, one per batch slot beyond the first (slot 0 runs on the thread
+// that calls lgicp_submit).  They live as long as the context: a thread's first HIP calls and
+// first allocations are slow, occasionally by milliseconds.
+struct SlotThreads {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::function<void(int)> job;  // called with the slot index
+  uint64_t generation = 0;
+  int wanted = 0;   // helpers that take part in the current job (slots 1..wanted)
+  int pending = 0;
+  bool stop = false;
+
+  void start(int n_helpers) {
+    for (int k = 1; k <= n_helpers; ++k)
+      threads.emplace_back([this, k] {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(int)> fn;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_job.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            if (k > wanted) continue;
+            fn = job;
+          }
+          fn(k);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            --pending;
+          }
+          cv_done.notify_all();
+        }
+      });
+  }
+  // runs fn(1..n) on the helpers; returns at once
+  void post(int n, std::function<void(int)> fn) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = std::move(fn);
+      wanted = pending = std::min<int>(n, (int)threads.size());
+      ++generation;
+    }
+    cv_job.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_job.notify_all();
+    for (std::thread& t : threads) t.join();
+    threads.clear();
+  }
+};
+
 struct lgicp_ctx {
   lgicp_config cfg;
   std::unordered_map<uint64_t, Keyframe> scans;
@@ -150,6 +215,7 @@ struct lgicp_ctx {
   // parts of a submit in flight at once, one stream each (the GPU exposes 4 hardware queues
   // per process); reserved[7] overrides
   int n_slots = 4;
+  SlotThreads helpers;
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
   DevBuf<IndexSegDev> d_isegs;   // for keyframe registration
   DevBuf<CloudDev> d_reg_cloud;

@@ -20,7 +20,8 @@ def main():
     c = capi.Context(init_method=capi.INIT_IDENTITY, iterations=iters, reserved=(capi.C.c_int * 8)(*res))
     wl.register(c)
     packed = c.pack_candidates(wl.candidates())
-    for rep in range(4):
+    reps = kw.pop("reps", 4)
+    for rep in range(reps):
         t = time.time()
         out = c.submit_packed(packed)
         dt = time.time() - t
