@@ -70,8 +70,6 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--settle", type=int, default=10,
-                    help="untimed submits before the warm-up steps (process start-up effects)")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--pairs", type=int, default=None)
     ap.add_argument("--points", type=int, default=None)
@@ -133,11 +131,6 @@ def main():
             torch.cuda.synchronize()
         return out
 
-    # The first submits of a process see 3-4 ms stalls while the HIP runtime grows its per-queue
-    # resources (measured: submits 1-8, never later).  They are setup, like keyframe
-    # registration: run until that has settled, then the W warm-up steps the contract asks for.
-    for _ in range(args.settle):
-        step()
     for _ in range(args.warmup):
         res = step()
     nn_ms = nn_launches = nn_evals = nn_exec = 0.0

@@ -1,5 +1,7 @@
 // cloud_ops.hip — HBM-bound per-point kernels: per-point covariances from normals, scan
 // accumulation, initial-guess transform, normalisation constants.
+#include <algorithm>
+
 #include "lgicp_device.h"
 
 namespace lgicp {
@@ -15,6 +17,25 @@ hipError_t launch_pad_fill(float4* xyz, int n, int n_pad, hipStream_t stream) {
   if (n_pad <= n) return hipSuccess;
   hipLaunchKernelGGL(pad_fill_kernel, dim3((n_pad - n + 255) / 256), dim3(256), 0, stream, xyz, n,
                      n_pad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain copy, 16 bytes per lane.  Tables and results of a batch travel between pinned host
+// memory and the device through this kernel rather than through hipMemcpyAsync: the copy is then
+// one more kernel in the stream's order (the runtime's copy path was measured to block the
+// calling host thread for milliseconds during the first submits of a process).
+__global__ void copy16_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+       i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+hipError_t launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  const size_t n16 = (bytes + 15) / 16;  // both buffers are padded to 16 bytes by their owners
+  if (n16 == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<size_t>(1024, (n16 + 255) / 256);
+  hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, stream, (uint4*)dst, (const uint4*)src, n16);
   return hipGetLastError();
 }
 

@@ -624,7 +624,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   HIP_TRY(ctx, hipMemsetAsync(W->d_counters.p, 0, sizeof(unsigned long long) * NN_COUNTER_SLOTS, st));
   // the staging buffer is rewritten only by the next batch of this slot, which starts after this
   // batch's last synchronisation
-  HIP_TRY(ctx, hipMemcpyAsync(dpar, W->h_params, used_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, launch_copy16(dpar, W->h_params, used_bytes, st));
 
   W->ev_used = 0;
   hipEvent_t ev_begin = W->event(), ev_prep = W->event();
@@ -846,7 +846,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     char* h = reinterpret_cast<char*>(W->h_maps[k]);
     std::memcpy(h, h_bmap_red.data(), sizeof(int4) * h_bmap_red.size());
     std::memcpy(h + red_region, h_bmap_nn.data(), sizeof(int4) * h_bmap_nn.size());
-    HIP_TRY(ctx, hipMemcpyAsync(d_bmap_red, h, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, launch_copy16(d_bmap_red, h, bytes, st));
     return LGICP_OK;
   };
   if (n_inactive0) {
@@ -959,10 +959,9 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   const double* const h_post = reinterpret_cast<const double*>(W->h_results);
   const unsigned long long* const h_counters =
       reinterpret_cast<const unsigned long long*>(W->h_results + o_hcount);
-  HIP_TRY(ctx, hipMemcpyAsync(W->h_results, W->d_partials.p, post_bytes, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->h_results + o_hstate, d_state, state_bytes, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(W->h_results + o_hcount, W->d_counters.p, counter_bytes,
-                              hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, launch_copy16(W->h_results, W->d_partials.p, post_bytes, st));
+  HIP_TRY(ctx, launch_copy16(W->h_results + o_hstate, d_state, state_bytes, st));
+  HIP_TRY(ctx, launch_copy16(W->h_results + o_hcount, W->d_counters.p, counter_bytes, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   std::memcpy(h_state.data(), W->h_results + o_hstate, state_bytes);
   since("results downloaded");
