@@ -233,7 +233,9 @@ def main():
                         "pass; the 157.3 TFLOP/s peak assumes packed FMA.  The pruned kernel "
                         "returns the same indices while evaluating only the distances its box "
                         "tests cannot rule out, so achieved may exceed the peak; executed_* count "
-                        "the distances it really evaluated (device counter).",
+                        "the distances it really evaluated (device counter).  A submit runs as up "
+                        "to four parts on four streams: a launch covers one part and shares the GPU "
+                        "with the other parts' kernels for most of its duration.",
             },
             "roofline_reduce": {
                 "bound": "hbm",
@@ -247,7 +249,9 @@ def main():
                 "bytes_per_launch": red_bytes / max(red_launches, 1),
                 "note": "algorithmic bytes: 44 B per source point read (16 p + 4 index + 24 C1) "
                         "+ 40 B per correspondence inside corr_dist (16 q + 24 C2), f32 minimum "
-                        "layout; the kernel keeps covariances in f64 (the reference's type)",
+                        "layout; the kernel keeps covariances in f64 (the reference's type).  A launch "
+                        "covers one of up to four concurrent parts of the submit and shares the GPU "
+                        "with the other parts' kernels.",
             },
         }
         if not args.no_cpu and world == 1:
