@@ -245,30 +245,43 @@ __device__ double quad_eval(const QuadForm& q, const double Th[12], double* grad
   return f;
 }
 
-__device__ bool chol6_solve(const double H[36], const double g[6], double dx[6]) {
-  double L[36];
-  for (int i = 0; i < 36; ++i) L[i] = 0;
+// Solves H dx = g by Cholesky (H symmetric 6x6, lower triangle read).  Every loop has constant
+// bounds and is unrolled, so L lives in registers (run-time indexing would put it in scratch
+// memory, and this code runs on the latency-critical path of every outer iteration).
+__device__ __forceinline__ bool chol6_solve(const double* __restrict__ H, const double* __restrict__ g,
+                                            double dx[6]) {
+  double L[21];  // row-major lower triangle: (i, j) at i (i + 1) / 2 + j
+  double inv[6];  // 1 / L(j, j): one division per column instead of one per entry
+#pragma unroll
   for (int i = 0; i < 6; ++i)
+#pragma unroll
     for (int j = 0; j <= i; ++j) {
       double s = H[i * 6 + j];
-      for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
       if (i == j) {
         if (!(s > 0)) return false;
-        L[i * 6 + i] = sqrt(s);
+        const double d = sqrt(s);
+        L[i * (i + 1) / 2 + i] = d;
+        inv[i] = 1.0 / d;
       } else {
-        L[i * 6 + j] = s / L[j * 6 + j];
+        L[i * (i + 1) / 2 + j] = s * inv[j];
       }
     }
   double y[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     double s = g[i];
-    for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
-    y[i] = s / L[i * 6 + i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[i * (i + 1) / 2 + k] * y[k];
+    y[i] = s * inv[i];
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
     double s = y[i];
-    for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * dx[k];
-    dx[i] = s / L[i * 6 + i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= L[k * (k + 1) / 2 + i] * dx[k];
+    dx[i] = s * inv[i];
   }
   return true;
 }
@@ -310,15 +323,14 @@ __device__ void apply_state(const double x[6], float T[16]) {
   T[15] = 1.f;
 }
 
-// FNV-1a over the 16 float words of a transformation
+// 64-bit hash of the 16 float words of a transformation (multiply-xorshift per word)
 __device__ unsigned long long hash_T(const float T[16]) {
   unsigned long long h = 1469598103934665603ull;
+#pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const unsigned w = __float_as_uint(T[i]);
-    for (int b = 0; b < 4; ++b) {
-      h ^= (w >> (8 * b)) & 0xFFu;
-      h *= 1099511628211ull;
-    }
+    h ^= (unsigned long long)__float_as_uint(T[i]);
+    h *= 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
   }
   return h;
 }
@@ -467,16 +479,24 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
         L.H[lane] = 2.0 * acc;
       }
       __syncthreads();
-      double H[36], g[6], dx[6];
-      for (int i = 0; i < 36; ++i) H[i] = L.H[i];
-      for (int i = 0; i < 6; ++i) g[i] = L.g[i];
-      if (!chol6_solve(H, g, dx)) break;
-      double step = 1.0, fn = f, xn[6];
+      double dx[6];
+      if (!chol6_solve(L.H, L.g, dx)) break;
+      double step = 1.0, fn = f, xn[6], gn[12];
       bool ok = false;
       for (int h = 0; h < 30; ++h) {
-        for (int c = 0; c < 6; ++c) xn[c] = x[c] + step * dx[c];
-        theta_of_x(xn, Th, dTh, false);
-        fn = quad_eval_wave(L, Theta0, qc, Th, nullptr, lane);
+        double reach = 0;
+        for (int c = 0; c < 6; ++c) {
+          xn[c] = x[c] + step * dx[c];
+          reach = fmax(reach, fabs(step * dx[c]));
+        }
+        // a trial closer to x than the convergence threshold below cannot change the outcome by
+        // more than that threshold; without this exit a solve that has already converged pays
+        // for all 30 halvings (each a full evaluation) before it gives up
+        if (reach < 1e-12) break;
+        // value, gradient and derivatives at the trial point in one go: an accepted point (the
+        // full step, almost always) is the next iteration's starting point as it is
+        theta_of_x(xn, Th, dTh, true);
+        fn = quad_eval_wave(L, Theta0, qc, Th, gn, lane);
         if (fn < f) {
           ok = true;
           break;
@@ -489,8 +509,8 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
         mx = fmax(mx, fabs(xn[c] - x[c]));
         x[c] = xn[c];
       }
-      theta_of_x(x, Th, dTh, true);
-      f = quad_eval_wave(L, Theta0, qc, Th, g12, lane);
+      f = fn;
+      for (int i = 0; i < 12; ++i) g12[i] = gn[i];
       if (mx < 1e-12) break;
     }
     apply_state(x, T);
