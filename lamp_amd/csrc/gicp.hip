@@ -30,16 +30,29 @@ __host__ __device__ constexpr int uu_slot(int k, int l) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RED_THREADS, 2) void gicp_reduce_kernel(
+// The statistics are sums over the correspondences of outer products: with
+//   a = (xx xy xz x yy yz y zz z 1 | r0 r1 r2)   (u u^T in uu_slot order, then the residual)
+//   b = (M00 M01 M02 M11 M12 M22 | Mr0 Mr1 Mr2 | 1)
+// Q is rows 0..9 x columns 0..5 of D = sum a b^T, the linear term rows (x, y, z, 1) x columns
+// 6..8, the constant D[10][6] + D[11][7] + D[12][8] and the count D[9][9].  That is a
+// (13 x m)(m x 10) matrix product with the correspondences as the contraction index, which the
+// f64 matrix pipe does as v_mfma_f64_16x16x4_f64: four correspondences per instruction, the
+// whole 16 x 16 accumulator in four f64 registers per lane - against 73 f64 accumulators per lane
+// when every lane sums its own points, which capped that version at two waves per SIMD while
+// it waited on its gathers.  Each lane still builds a and b of its own point; a wave passes them
+// through its private LDS rows so that lane l can feed A[l & 15][l >> 4] and B[l >> 4][l & 15].
+typedef double red_d4 __attribute__((ext_vector_type(4)));
+constexpr int RM_ROWS_A = 13, RM_ROWS_B = 10;
+constexpr int RM_STR = 65;  // doubles per staged row (64 points + 1: operand reads spread over the banks)
+
+__global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
     const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
     const PairState* __restrict__ st, const int4* __restrict__ bmap, double corr_dist2,
     double* __restrict__ partials) {
   // double-precision statistics: no float result of the reference is reproduced bit by bit
   // here, so multiply-adds may fuse (the float transformation arithmetic lives elsewhere)
 #pragma clang fp contract(fast)
-  __shared__ double sh[RED_THREADS / 64][NSTAT + 6];
-  constexpr int RED_ROW = 4 * 17;  // 64 partials of one statistic, 4 groups of 16 padded to 17
-  __shared__ double transpose[RED_THREADS / 64][16 * RED_ROW];
+  __shared__ double stage[RED_THREADS / 64][(RM_ROWS_A + RM_ROWS_B) * RM_STR];
   const int4 bm = bmap[blockIdx.x];
   const int pair = bm.x;
   const PairState& S = st[pair];
@@ -62,113 +75,120 @@ __global__ __launch_bounds__(RED_THREADS, 2) void gicp_reduce_kernel(
 #pragma unroll
   for (int i = 0; i < 12; ++i) Th[i] = (double)S.T[i];  // rows 0..2 of the 4x4, row-major
 
-  double acc[NSTAT - 1];
-#pragma unroll
-  for (int i = 0; i < NSTAT - 1; ++i) acc[i] = 0.0;
-  int m = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* const sa = stage[wave];
+  double* const sb = sa + RM_ROWS_A * RM_STR;
+  // operand slots of this lane; rows/columns past the used ones only feed unused outputs
+  const int orow = min(lane & 15, RM_ROWS_A - 1), ocol = min(lane & 15, RM_ROWS_B - 1);
+  const int ok = lane >> 4;
+  const double* const pa = sa + orow * RM_STR + ok;
+  const double* const pb = sb + ocol * RM_STR + ok;
+  red_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 
   const int n = P.n_src;
   const int per = (n + bm.z - 1) / bm.z;
   const int i0 = bm.y * per;
   const int i1 = min(n, i0 + per);
-  // the packed match of the next point is fetched one iteration ahead: the gathers that depend
-  // on it then start at the top of the iteration instead of a memory latency later
-  nnkey_t key_nxt = (i0 + (int)threadIdx.x < i1) ? P.keys[i0 + threadIdx.x] : NNKEY_NONE;
-  for (int i = i0 + threadIdx.x; i < i1; i += RED_THREADS) {
-    const nnkey_t key = key_nxt;
-    key_nxt = (i + RED_THREADS < i1) ? P.keys[i + RED_THREADS] : NNKEY_NONE;
-    if (key == NNKEY_NONE) continue;
+  for (int base = i0 + wave * 64; base < i1; base += RED_THREADS) {  // wave-uniform
+    const int i = base + lane;
+    double av[RM_ROWS_A], bv[RM_ROWS_B];
+#pragma unroll
+    for (int r = 0; r < RM_ROWS_A; ++r) av[r] = 0.0;
+#pragma unroll
+    for (int c = 0; c < RM_ROWS_B; ++c) bv[c] = 0.0;
+    const nnkey_t key = i < i1 ? P.keys[i] : NNKEY_NONE;
     const float d2 = __uint_as_float((unsigned)(key >> 32));
-    if (!((double)d2 < corr_dist2)) continue;  // gicp.hpp:483
-    const int j = (int)(key & 0xFFFFFFFFu);
-    const float4 pf = P.out[i];
-    const float4 qf = TC.xyz[j];
-    const double* c1 = SC.cov + 6 * (size_t)i;
-    const double* c2 = TC.cov + 6 * (size_t)j;
-    const double a00 = c1[0], a01 = c1[1], a02 = c1[2], a11 = c1[3], a12 = c1[4], a22 = c1[5];
-    // RC = R * C1
-    double RC[9];
+    if (key != NNKEY_NONE && (double)d2 < corr_dist2) {  // gicp.hpp:483
+      const int j = (int)(key & 0xFFFFFFFFu);
+      const float4 pf = P.out[i];
+      const float4 qf = TC.xyz[j];
+      const double* c1 = SC.cov + 6 * (size_t)i;
+      const double* c2 = TC.cov + 6 * (size_t)j;
+      const double a00 = c1[0], a01 = c1[1], a02 = c1[2], a11 = c1[3], a12 = c1[4], a22 = c1[5];
+      // RC = R * C1
+      double RC[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const double r0 = R[r * 3], r1 = R[r * 3 + 1], r2 = R[r * 3 + 2];
-      RC[r * 3 + 0] = r0 * a00 + r1 * a01 + r2 * a02;
-      RC[r * 3 + 1] = r0 * a01 + r1 * a11 + r2 * a12;
-      RC[r * 3 + 2] = r0 * a02 + r1 * a12 + r2 * a22;
-    }
-    // S = RC * R^T + C2 (symmetric)
-    double s00 = RC[0] * R[0] + RC[1] * R[1] + RC[2] * R[2] + c2[0];
-    double s01 = RC[0] * R[3] + RC[1] * R[4] + RC[2] * R[5] + c2[1];
-    double s02 = RC[0] * R[6] + RC[1] * R[7] + RC[2] * R[8] + c2[2];
-    double s11 = RC[3] * R[3] + RC[4] * R[4] + RC[5] * R[5] + c2[3];
-    double s12 = RC[3] * R[6] + RC[4] * R[7] + RC[5] * R[8] + c2[4];
-    double s22 = RC[6] * R[6] + RC[7] * R[7] + RC[8] * R[8] + c2[5];
-    // M = S^-1 by cofactors (Eigen's 3x3 inverse, gicp.hpp:493)
-    const double k00 = s11 * s22 - s12 * s12;
-    const double k01 = s02 * s12 - s01 * s22;
-    const double k02 = s01 * s12 - s02 * s11;
-    const double det = s00 * k00 + s01 * k01 + s02 * k02;
-    const double inv = 1.0 / det;
-    double M[6];
-    M[0] = k00 * inv;
-    M[1] = k01 * inv;
-    M[2] = k02 * inv;
-    M[3] = (s00 * s22 - s02 * s02) * inv;
-    M[4] = (s01 * s02 - s00 * s12) * inv;
-    M[5] = (s00 * s11 - s01 * s01) * inv;
-
-    const double u[4] = {(double)pf.x, (double)pf.y, (double)pf.z, 1.0};
-    const double r0 = (Th[0] * u[0] + Th[1] * u[1] + Th[2] * u[2] + Th[3]) - (double)qf.x;
-    const double r1 = (Th[4] * u[0] + Th[5] * u[1] + Th[6] * u[2] + Th[7]) - (double)qf.y;
-    const double r2 = (Th[8] * u[0] + Th[9] * u[1] + Th[10] * u[2] + Th[11]) - (double)qf.z;
-    const double Mr[3] = {M[0] * r0 + M[1] * r1 + M[2] * r2, M[1] * r0 + M[3] * r1 + M[4] * r2,
-                          M[2] * r0 + M[4] * r1 + M[5] * r2};
-    acc[72] += r0 * Mr[0] + r1 * Mr[1] + r2 * Mr[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) acc[60 + k * 3 + a] += u[k] * Mr[a];
-#pragma unroll
-      for (int l = k; l < 4; ++l) {
-        const double ukl = u[k] * u[l];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) acc[uu_slot(k, l) * 6 + e] += ukl * M[e];
+      for (int r = 0; r < 3; ++r) {
+        const double r0 = R[r * 3], r1 = R[r * 3 + 1], r2 = R[r * 3 + 2];
+        RC[r * 3 + 0] = r0 * a00 + r1 * a01 + r2 * a02;
+        RC[r * 3 + 1] = r0 * a01 + r1 * a11 + r2 * a12;
+        RC[r * 3 + 2] = r0 * a02 + r1 * a12 + r2 * a22;
       }
+      // S = RC * R^T + C2 (symmetric)
+      const double s00 = RC[0] * R[0] + RC[1] * R[1] + RC[2] * R[2] + c2[0];
+      const double s01 = RC[0] * R[3] + RC[1] * R[4] + RC[2] * R[5] + c2[1];
+      const double s02 = RC[0] * R[6] + RC[1] * R[7] + RC[2] * R[8] + c2[2];
+      const double s11 = RC[3] * R[3] + RC[4] * R[4] + RC[5] * R[5] + c2[3];
+      const double s12 = RC[3] * R[6] + RC[4] * R[7] + RC[5] * R[8] + c2[4];
+      const double s22 = RC[6] * R[6] + RC[7] * R[7] + RC[8] * R[8] + c2[5];
+      // M = S^-1 by cofactors (Eigen's 3x3 inverse, gicp.hpp:493)
+      const double k00 = s11 * s22 - s12 * s12;
+      const double k01 = s02 * s12 - s01 * s22;
+      const double k02 = s01 * s12 - s02 * s11;
+      const double det = s00 * k00 + s01 * k01 + s02 * k02;
+      const double inv = 1.0 / det;
+      bv[0] = k00 * inv;
+      bv[1] = k01 * inv;
+      bv[2] = k02 * inv;
+      bv[3] = (s00 * s22 - s02 * s02) * inv;
+      bv[4] = (s01 * s02 - s00 * s12) * inv;
+      bv[5] = (s00 * s11 - s01 * s01) * inv;
+      const double x = (double)pf.x, y = (double)pf.y, z = (double)pf.z;
+      const double r0 = (Th[0] * x + Th[1] * y + Th[2] * z + Th[3]) - (double)qf.x;
+      const double r1 = (Th[4] * x + Th[5] * y + Th[6] * z + Th[7]) - (double)qf.y;
+      const double r2 = (Th[8] * x + Th[9] * y + Th[10] * z + Th[11]) - (double)qf.z;
+      bv[6] = bv[0] * r0 + bv[1] * r1 + bv[2] * r2;
+      bv[7] = bv[1] * r0 + bv[3] * r1 + bv[4] * r2;
+      bv[8] = bv[2] * r0 + bv[4] * r1 + bv[5] * r2;
+      bv[9] = 1.0;
+      av[0] = x * x, av[1] = x * y, av[2] = x * z, av[3] = x;
+      av[4] = y * y, av[5] = y * z, av[6] = y;
+      av[7] = z * z, av[8] = z, av[9] = 1.0;
+      av[10] = r0, av[11] = r1, av[12] = r2;
     }
-    ++m;
+#pragma unroll
+    for (int r = 0; r < RM_ROWS_A; ++r) sa[r * RM_STR + lane] = av[r];
+#pragma unroll
+    for (int c = 0; c < RM_ROWS_B; ++c) sb[c * RM_STR + lane] = bv[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * t], pb[4 * t], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * t + 4], pb[4 * t + 4], acc1, 0, 0, 0);
+    }
+    // the next round's stores must not overtake these reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 
-  // Wave-level sums through LDS, 16 statistics at a time: every lane stores its 16 partials
-  // (statistic-major, padded rows), then lane (v, part) = (lane / 4, lane % 4) adds the 16
-  // partials of statistic v that lanes 16*part .. 16*part+15 stored, and two shuffles combine the
-  // four parts.  74 x 6 dependent shuffle steps become 80 stores, 80 loads and 10 shuffles.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* const tr = transpose[wave];
-  const int v = lane >> 2, part = lane & 3;
+  // D[row][col] sits in lane (row & 3) * 16 + col, register row >> 2; each wave parks its D in
+  // its own staging rows, then one thread per statistic adds the four waves in order
+  const red_d4 acc = acc0 + acc1;
 #pragma unroll
-  for (int c = 0; c < (NSTAT + 15) / 16; ++c) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int idx = c * 16 + e;
-      const double val = idx < NSTAT - 1 ? acc[idx < NSTAT - 1 ? idx : 0] : (idx == NSTAT - 1 ? (double)m : 0.0);
-      tr[e * RED_ROW + (lane >> 4) * 17 + (lane & 15)] = val;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    double sum = 0;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) sum += tr[v * RED_ROW + part * 17 + t];
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
-    if (part == 0 && c * 16 + v < NSTAT) sh[wave][c * 16 + v] = sum;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
+  for (int q = 0; q < 4; ++q) sa[q * 64 + lane] = acc[q];
   __syncthreads();
   if (threadIdx.x < NSTAT) {
+    const int sidx = threadIdx.x;
+    auto D = [&](int w, int row, int col) {
+      return stage[w][(row >> 2) * 64 + (row & 3) * 16 + col];
+    };
     double s = 0;
 #pragma unroll
-    for (int w = 0; w < RED_THREADS / 64; ++w) s += sh[w][threadIdx.x];
-    partials[((size_t)pair * RED_MAX_CHUNKS + bm.y) * NSTAT + threadIdx.x] = s;
+    for (int w = 0; w < RED_THREADS / 64; ++w) {
+      if (sidx < 60) {
+        s += D(w, sidx / 6, sidx % 6);
+      } else if (sidx < 72) {
+        const int k = (sidx - 60) / 3, a = (sidx - 60) % 3;
+        s += D(w, uu_slot(k, 3), 6 + a);
+      } else if (sidx == 72) {
+        s += (D(w, 10, 6) + D(w, 11, 7)) + D(w, 12, 8);
+      } else {
+        s += D(w, 9, 9);
+      }
+    }
+    partials[((size_t)pair * RED_MAX_CHUNKS + bm.y) * NSTAT + sidx] = s;
   }
 }
 
