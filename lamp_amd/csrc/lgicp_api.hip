@@ -356,33 +356,30 @@ void guess_from_pose(const hm::Pose& p, bool with_translation, float g[16]) {
 }
 
 // runs one device batch; results for bp.pairs[i] go to out[bp.pairs[i].cand]
-int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate* cand,
-              lgicp_result* out) {
-  const bool trace_t = std::getenv("LGICP_TRACE") != nullptr;
-  const auto t_enter = std::chrono::steady_clock::now();
-  auto since = [&](const char* what) {
-    if (trace_t)
-      std::fprintf(stderr, "[lgicp] slot %d %s at %.3f ms\n", (int)(W - ctx->slot), what,
-                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
-  };
-
-  const lgicp_config& cfg = ctx->cfg;
-  hipStream_t st = W->stream;
-  const int n_pairs = (int)bp.pairs.size();
-  const int n_clouds = (int)bp.clouds.size();
-  if (n_pairs == 0) return LGICP_OK;
-
-  // ---- device scratch ----------------------------------------------------------------------
-  size_t pair_bytes = 0;
-  for (auto& p : bp.pairs) pair_bytes += (size_t)bp.clouds[p.src_cloud].n * 24 + 512;
-  HIP_TRY(ctx, W->arena.reserve(bp.bytes + pair_bytes + 4096));
-  Arena ar{W};
-
-  std::vector<CloudDev> h_clouds((size_t)n_clouds);
-  std::vector<SegmentDev> h_segs;
-  std::vector<IndexSegDev> h_isegs;
+// Device-side description of every distinct cloud of a batch.  Keyframes that need no
+// accumulation point straight at their resident buffers; an accumulated cloud gets arena space
+// for points, normals, covariances and an index that is the concatenation of its members'
+// segments, plus the copy/transform segments (AccumulateScans, IcpLoopComputation.cc:910-947)
+// that will fill it.
+struct CloudTables {
+  std::vector<CloudDev> clouds;
+  std::vector<SegmentDev> segs;
+  std::vector<IndexSegDev> isegs;
   std::vector<int> normal_jobs;  // accumulated clouds whose normals have to be estimated
   int max_seg_n = 0, max_cloud_n = 0, max_iseg_n = 0;
+};
+
+void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t) {
+  const lgicp_config& cfg = ctx->cfg;
+  const int n_clouds = (int)bp.clouds.size();
+  t->clouds.resize((size_t)n_clouds);
+  std::vector<CloudDev>& h_clouds = t->clouds;
+  std::vector<SegmentDev>& h_segs = t->segs;
+  std::vector<IndexSegDev>& h_isegs = t->isegs;
+  std::vector<int>& normal_jobs = t->normal_jobs;
+  int& max_seg_n = t->max_seg_n;
+  int& max_cloud_n = t->max_cloud_n;
+  int& max_iseg_n = t->max_iseg_n;
   for (int c = 0; c < n_clouds; ++c) {
     CloudPlan& cp = bp.clouds[c];
     const Keyframe& kf = ctx->scans.at(cp.key);
@@ -476,6 +473,258 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
       }
     }
   }
+
+}
+
+// FEATURES / TEASERPP initialisation (IcpLoopComputation.cc:517-531, 650-705, 949-1081): Harris
+// keypoints and FPFH descriptors once per distinct cloud of the batch, then SAC-IA or TEASER++
+// per pair starting from the odometry guess.  Rewrites the pairs' guesses (and the state of
+// pairs that SAC-IA rejects: keypoint fitness at or above the threshold) in the host tables;
+// the caller uploads them again.
+int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vector<CloudDev>& h_clouds,
+                             const lgicp_candidate* cand, lgicp_result* out,
+                             std::vector<PairDev>& h_pairs, std::vector<PairState>& h_state,
+                             std::vector<char>& init_rejected) {
+  const lgicp_config& cfg = ctx->cfg;
+  const int n_pairs = (int)bp.pairs.size();
+  std::map<int, CloudFeatures> feats;
+  for (int p = 0; p < n_pairs; ++p)
+    for (int c : {bp.pairs[p].src_cloud, bp.pairs[p].tgt_cloud})
+      if (!feats.count(c)) {
+        const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm_x,
+                                              h_clouds[c].n, &feats[c]);
+        if (rc != LGICP_OK) return rc;
+      }
+  if (cfg.init_method == LGICP_INIT_TEASERPP) {
+    // IcpLoopComputation.cc:528-531: never rejects; keeps the odometry guess unless the
+    // TEASER++ transform explains the descriptor matches at least as well.  The matches and
+    // their consistency graph come from the device one pair after the other; clique and
+    // rotation search are host work and run for a window of pairs on as many threads.
+    // The cost of a pair grows with the square of its clique, so pairs are handed out one
+    // by one: this thread produces (device work), up to 16 workers consume; at most `window`
+    // graphs or 1 GiB of them wait or are being solved at any time.
+    const int window = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const bool trace = std::getenv("LGICP_TRACE") != nullptr;  // diagnostics on stderr
+    struct Slot {
+      TeaserJob job;
+      int pair = -1;
+      size_t bytes = 0;
+    };
+    std::vector<Slot> slots((size_t)window);
+    std::vector<int> free_slots, ready;
+    for (int j = 0; j < window; ++j) free_slots.push_back(j);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t held_bytes = 0;
+    bool closed = false;
+    std::atomic<int> rc_finish{LGICP_OK};
+    auto worker = [&]() {
+      for (;;) {
+        int j;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return !ready.empty() || closed; });
+          if (ready.empty()) return;
+          j = ready.back();
+          ready.pop_back();
+        }
+        const int p = slots[j].pair;
+        const PairPlan& pp = bp.pairs[p];
+        float T0[16];
+        int used = 0, nc = 0;
+        const auto t_a = std::chrono::steady_clock::now();
+        const int rc = teaser_finish(ctx, slots[j].job, pp.guess, T0, &used, &nc);
+        if (rc != LGICP_OK) rc_finish.store(rc);
+        if (trace)
+          std::fprintf(stderr, "[lgicp] teaser pair %d: %d matches, clique %d, host %.1f ms\n", p,
+                       slots[j].job.n_matches, nc,
+                       1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count());
+        out[pp.cand].init_fitness = used ? (double)nc : 0.0;
+        std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
+        if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          held_bytes -= slots[j].bytes;
+          free_slots.push_back(j);
+        }
+        cv.notify_all();
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int j = 0; j < window; ++j) pool.emplace_back(worker);
+    int rc_prepare = LGICP_OK;
+    for (int p = 0; p < n_pairs && rc_prepare == LGICP_OK; ++p) {
+      int j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !free_slots.empty() && held_bytes < (1ull << 30); });
+        j = free_slots.back();
+        free_slots.pop_back();
+      }
+      const PairPlan& pp = bp.pairs[p];
+      rc_prepare = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], &slots[j].job);
+      slots[j].pair = p;
+      slots[j].bytes = slots[j].job.graph.bits.size() * sizeof(uint64_t);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc_prepare == LGICP_OK) {
+          held_bytes += slots[j].bytes;
+          ready.push_back(j);
+        } else {
+          free_slots.push_back(j);
+        }
+      }
+      cv.notify_all();
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      closed = true;
+    }
+    cv.notify_all();
+    for (std::thread& t : pool) t.join();
+    if (rc_prepare != LGICP_OK) return rc_prepare;
+    if (rc_finish.load() != LGICP_OK) return rc_finish.load();
+  }
+  for (int p = 0; p < n_pairs && cfg.init_method == LGICP_INIT_FEATURES; ++p) {
+    const PairPlan& pp = bp.pairs[p];
+    float T0[16];
+    double score = 0;
+    // one fixed sampling sequence per (key_from, key_to): results do not depend on how the
+    // candidates were batched
+    const uint32_t seed = 0x5AC1A000u ^ (uint32_t)(cand[pp.cand].key_from * 2654435761ull) ^
+                          (uint32_t)(cand[pp.cand].key_to * 40503ull);
+    const int rc = sac_align_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], pp.guess,
+                                    seed, T0, &score);
+    if (rc != LGICP_OK) return rc;
+    out[pp.cand].init_fitness = score;
+    std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
+    if (!(score < cfg.sac_fitness_score_threshold)) {
+      init_rejected[p] = 1;
+      h_state[p].active = 0;
+      h_state[p].failed = 1;
+    }
+    if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
+  }
+  return LGICP_OK;
+}
+
+// What PerformAlignment does with a finished alignment (IcpLoopComputation.cc:568-640): status
+// gates (finite, converged, fitness, transform thresholds), the inverse pose and its covariance
+// / information matrix.  O(1) 6x6 algebra per pair, on the host as in the reference.  h_post
+// holds the fitness / Ap partial sums of the batch, [pair][RED_MAX_CHUNKS][NPOST].
+void finish_pairs(const lgicp_config& cfg, const BatchPlan& bp, const std::vector<PairDev>& h_pairs,
+                  const std::vector<PairState>& h_state, const std::vector<int>& h_ints,
+                  const double* h_post, const std::vector<char>& init_rejected, lgicp_result* out,
+                  lgicp_stats& S) {
+  const int n_pairs = (int)bp.pairs.size();
+  for (int p = 0; p < n_pairs; ++p) {
+    const PairPlan& pp = bp.pairs[p];
+    const PairState& s = h_state[p];
+    lgicp_result& r = out[pp.cand];
+    r.iterations = s.iterations;
+    r.converged = s.converged;
+    r.n_correspondences = s.m;
+    std::memcpy(r.T_icp, s.Tfinal, sizeof(r.T_icp));
+    std::memcpy(r.T_init, h_pairs[p].guess, sizeof(r.T_init));
+    if (init_rejected[p]) {
+      r.status = LGICP_PAIR_INIT_REJECTED;
+      continue;
+    }
+    S.outer_iterations += (uint64_t)s.iterations;
+    S.reduce_points += (double)h_pairs[p].n_src * (double)s.iterations;
+    S.reduce_inliers += s.m_sum;
+    S.nn_distance_evals +=
+        (double)h_pairs[p].n_src * (double)h_pairs[p].n_tgt * (double)(s.iterations + 1);
+    double post[NPOST] = {0};
+    for (int c = 0; c < h_ints[p]; ++c)
+      for (int k = 0; k < NPOST; ++k) post[k] += h_post[((size_t)p * RED_MAX_CHUNKS + c) * NPOST + k];
+    const float* T = s.Tfinal;
+    bool finite = post[2] == 0.0;
+    for (int i = 0; i < 16; ++i) finite = finite && std::isfinite(T[i]);
+    if (cfg.covariance_method == LGICP_COV_POINT2PLANE && !finite) {
+      r.status = LGICP_PAIR_NONFINITE;
+      continue;
+    }
+    hm::Pose delta;
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) delta.R[a * 3 + b] = (double)T[a * 4 + b];
+      delta.t[a] = (double)T[a * 4 + 3];
+    }
+    r.fitness = post[1] > 0 ? post[0] / post[1] : 1.7976931348623157e308;
+    if (!s.converged) {
+      r.status = LGICP_PAIR_NOT_CONVERGED;
+      continue;
+    }
+    if (r.fitness > cfg.max_tolerable_fitness) {
+      r.status = LGICP_PAIR_FITNESS;
+      continue;
+    }
+    {
+      double xi[6];
+      hm::logmap(hm::between(pp.pose21_odom, delta), xi);
+      const double trans_diff = std::sqrt(xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5]);
+      const double rot_diff = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
+      if (cfg.transform_thresholding &&
+          (trans_diff > cfg.max_translation || rot_diff > cfg.max_rotation_deg * M_PI / 180.0)) {
+        r.status = LGICP_PAIR_TRANSFORM;
+        continue;
+      }
+    }
+    const hm::Pose inv = hm::inverse(delta);
+    std::memcpy(r.delta_R, inv.R, sizeof(r.delta_R));
+    std::memcpy(r.delta_t, inv.t, sizeof(r.delta_t));
+    hm::quat_from_R(inv.R, r.delta_q);
+    double Ap[36];
+    {
+      int k = 3;
+      for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) Ap[a * 6 + b] = Ap[b * 6 + a] = post[k++];
+    }
+    if (cfg.use_fixed_covariances) {
+      hm::fixed_covariance(cfg.laser_lc_rot_sigma, cfg.laser_lc_trans_sigma, r.covariance);
+      hm::inverse6(r.covariance, r.information);
+    } else if (cfg.covariance_method == LGICP_COV_POINT2POINT) {
+      hm::point_point_covariance(Ap /* = H */, r.fitness, r.covariance);
+      hm::inverse6(r.covariance, r.information);
+    } else {
+      hm::point_plane_covariance(Ap, cfg.laser_lc_rot_sigma, cfg.laser_lc_trans_sigma,
+                                 r.covariance);
+      for (int i = 0; i < 36; ++i) r.information[i] = Ap[i] / (0.05 * 0.05);
+    }
+    r.status = LGICP_PAIR_OK;
+    S.pairs_ok++;
+  }
+}
+
+int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate* cand,
+              lgicp_result* out) {
+  const bool trace_t = std::getenv("LGICP_TRACE") != nullptr;
+  const auto t_enter = std::chrono::steady_clock::now();
+  auto since = [&](const char* what) {
+    if (trace_t)
+      std::fprintf(stderr, "[lgicp] slot %d %s at %.3f ms\n", (int)(W - ctx->slot), what,
+                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count());
+  };
+
+  const lgicp_config& cfg = ctx->cfg;
+  hipStream_t st = W->stream;
+  const int n_pairs = (int)bp.pairs.size();
+  const int n_clouds = (int)bp.clouds.size();
+  if (n_pairs == 0) return LGICP_OK;
+
+  // ---- device scratch ----------------------------------------------------------------------
+  size_t pair_bytes = 0;
+  for (auto& p : bp.pairs) pair_bytes += (size_t)bp.clouds[p.src_cloud].n * 24 + 512;
+  HIP_TRY(ctx, W->arena.reserve(bp.bytes + pair_bytes + 4096));
+  Arena ar{W};
+
+  CloudTables tables;
+  build_cloud_tables(ctx, bp, ar, &tables);
+  std::vector<CloudDev>& h_clouds = tables.clouds;
+  std::vector<SegmentDev>& h_segs = tables.segs;
+  std::vector<IndexSegDev>& h_isegs = tables.isegs;
+  const std::vector<int>& normal_jobs = tables.normal_jobs;
+  const int max_seg_n = tables.max_seg_n, max_iseg_n = tables.max_iseg_n;
 
   // the large host tables live in the slot: their pages stay mapped from batch to batch
   std::vector<PairDev>& h_pairs = W->v_pairs;
@@ -652,130 +901,11 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   // covariances from normals and the NormalizePCloud constants were derived when the keyframes
   // were registered; accumulated clouds received their members' covariances in launch_assemble
 
-  // ---- FEATURES / TEASERPP initialisation (IcpLoopComputation.cc:517-531, 650-705, 949-1081) --
-  // Harris keypoints and FPFH descriptors once per distinct cloud of the batch, SAC-IA or
-  // TEASER++ per pair starting from the odometry guess; with SAC-IA a pair whose keypoint
-  // fitness reaches the threshold is dropped before GICP.
+  // ---- FEATURES / TEASERPP initialisation -----------------------------------------------------
   std::vector<char> init_rejected((size_t)n_pairs, 0);
   if (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP) {
-    std::map<int, CloudFeatures> feats;
-    for (int p = 0; p < n_pairs; ++p)
-      for (int c : {bp.pairs[p].src_cloud, bp.pairs[p].tgt_cloud})
-        if (!feats.count(c)) {
-          const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm_x,
-                                                h_clouds[c].n, &feats[c]);
-          if (rc != LGICP_OK) return rc;
-        }
-    if (cfg.init_method == LGICP_INIT_TEASERPP) {
-      // IcpLoopComputation.cc:528-531: never rejects; keeps the odometry guess unless the
-      // TEASER++ transform explains the descriptor matches at least as well.  The matches and
-      // their consistency graph come from the device one pair after the other; clique and
-      // rotation search are host work and run for a window of pairs on as many threads.
-      // The cost of a pair grows with the square of its clique, so pairs are handed out one
-      // by one: this thread produces (device work), up to 16 workers consume; at most `window`
-      // graphs or 1 GiB of them wait or are being solved at any time.
-      const int window = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-      const bool trace = std::getenv("LGICP_TRACE") != nullptr;  // diagnostics on stderr
-      struct Slot {
-        TeaserJob job;
-        int pair = -1;
-        size_t bytes = 0;
-      };
-      std::vector<Slot> slots((size_t)window);
-      std::vector<int> free_slots, ready;
-      for (int j = 0; j < window; ++j) free_slots.push_back(j);
-      std::mutex mu;
-      std::condition_variable cv;
-      size_t held_bytes = 0;
-      bool closed = false;
-      std::atomic<int> rc_finish{LGICP_OK};
-      auto worker = [&]() {
-        for (;;) {
-          int j;
-          {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !ready.empty() || closed; });
-            if (ready.empty()) return;
-            j = ready.back();
-            ready.pop_back();
-          }
-          const int p = slots[j].pair;
-          const PairPlan& pp = bp.pairs[p];
-          float T0[16];
-          int used = 0, nc = 0;
-          const auto t_a = std::chrono::steady_clock::now();
-          const int rc = teaser_finish(ctx, slots[j].job, pp.guess, T0, &used, &nc);
-          if (rc != LGICP_OK) rc_finish.store(rc);
-          if (trace)
-            std::fprintf(stderr, "[lgicp] teaser pair %d: %d matches, clique %d, host %.1f ms\n", p,
-                         slots[j].job.n_matches, nc,
-                         1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count());
-          out[pp.cand].init_fitness = used ? (double)nc : 0.0;
-          std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
-          if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
-          {
-            std::lock_guard<std::mutex> lk(mu);
-            held_bytes -= slots[j].bytes;
-            free_slots.push_back(j);
-          }
-          cv.notify_all();
-        }
-      };
-      std::vector<std::thread> pool;
-      for (int j = 0; j < window; ++j) pool.emplace_back(worker);
-      int rc_prepare = LGICP_OK;
-      for (int p = 0; p < n_pairs && rc_prepare == LGICP_OK; ++p) {
-        int j;
-        {
-          std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return !free_slots.empty() && held_bytes < (1ull << 30); });
-          j = free_slots.back();
-          free_slots.pop_back();
-        }
-        const PairPlan& pp = bp.pairs[p];
-        rc_prepare = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], &slots[j].job);
-        slots[j].pair = p;
-        slots[j].bytes = slots[j].job.graph.bits.size() * sizeof(uint64_t);
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          if (rc_prepare == LGICP_OK) {
-            held_bytes += slots[j].bytes;
-            ready.push_back(j);
-          } else {
-            free_slots.push_back(j);
-          }
-        }
-        cv.notify_all();
-      }
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        closed = true;
-      }
-      cv.notify_all();
-      for (std::thread& t : pool) t.join();
-      if (rc_prepare != LGICP_OK) return rc_prepare;
-      if (rc_finish.load() != LGICP_OK) return rc_finish.load();
-    }
-    for (int p = 0; p < n_pairs && cfg.init_method == LGICP_INIT_FEATURES; ++p) {
-      const PairPlan& pp = bp.pairs[p];
-      float T0[16];
-      double score = 0;
-      // one fixed sampling sequence per (key_from, key_to): results do not depend on how the
-      // candidates were batched
-      const uint32_t seed = 0x5AC1A000u ^ (uint32_t)(cand[pp.cand].key_from * 2654435761ull) ^
-                            (uint32_t)(cand[pp.cand].key_to * 40503ull);
-      const int rc = sac_align_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], pp.guess,
-                                      seed, T0, &score);
-      if (rc != LGICP_OK) return rc;
-      out[pp.cand].init_fitness = score;
-      std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
-      if (!(score < cfg.sac_fitness_score_threshold)) {
-        init_rejected[p] = 1;
-        h_state[p].active = 0;
-        h_state[p].failed = 1;
-      }
-      if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
-    }
+    const int rc = initialise_from_features(ctx, bp, h_clouds, cand, out, h_pairs, h_state, init_rejected);
+    if (rc != LGICP_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDev) * n_pairs,
                                 hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(d_state, h_state.data(), sizeof(PairState) * n_pairs,
@@ -996,84 +1126,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   S.last_nn_kernel_ms = nn_final_ms;
   S.last_nn_evals_per_launch = evals_per_pass;
 
-  // ---- per-pair host post-processing (IcpLoopComputation.cc:568-640) -----------------------------
-  for (int p = 0; p < n_pairs; ++p) {
-    const PairPlan& pp = bp.pairs[p];
-    const PairState& s = h_state[p];
-    lgicp_result& r = out[pp.cand];
-    r.iterations = s.iterations;
-    r.converged = s.converged;
-    r.n_correspondences = s.m;
-    std::memcpy(r.T_icp, s.Tfinal, sizeof(r.T_icp));
-    std::memcpy(r.T_init, h_pairs[p].guess, sizeof(r.T_init));
-    if (init_rejected[p]) {
-      r.status = LGICP_PAIR_INIT_REJECTED;
-      continue;
-    }
-    S.outer_iterations += (uint64_t)s.iterations;
-    S.reduce_points += (double)h_pairs[p].n_src * (double)s.iterations;
-    S.reduce_inliers += s.m_sum;
-    S.nn_distance_evals +=
-        (double)h_pairs[p].n_src * (double)h_pairs[p].n_tgt * (double)(s.iterations + 1);
-    double post[NPOST] = {0};
-    for (int c = 0; c < h_ints[p]; ++c)
-      for (int k = 0; k < NPOST; ++k) post[k] += h_post[((size_t)p * RED_MAX_CHUNKS + c) * NPOST + k];
-    const float* T = s.Tfinal;
-    bool finite = post[2] == 0.0;
-    for (int i = 0; i < 16; ++i) finite = finite && std::isfinite(T[i]);
-    if (cfg.covariance_method == LGICP_COV_POINT2PLANE && !finite) {
-      r.status = LGICP_PAIR_NONFINITE;
-      continue;
-    }
-    hm::Pose delta;
-    for (int a = 0; a < 3; ++a) {
-      for (int b = 0; b < 3; ++b) delta.R[a * 3 + b] = (double)T[a * 4 + b];
-      delta.t[a] = (double)T[a * 4 + 3];
-    }
-    r.fitness = post[1] > 0 ? post[0] / post[1] : 1.7976931348623157e308;
-    if (!s.converged) {
-      r.status = LGICP_PAIR_NOT_CONVERGED;
-      continue;
-    }
-    if (r.fitness > cfg.max_tolerable_fitness) {
-      r.status = LGICP_PAIR_FITNESS;
-      continue;
-    }
-    {
-      double xi[6];
-      hm::logmap(hm::between(pp.pose21_odom, delta), xi);
-      const double trans_diff = std::sqrt(xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5]);
-      const double rot_diff = std::sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
-      if (cfg.transform_thresholding &&
-          (trans_diff > cfg.max_translation || rot_diff > cfg.max_rotation_deg * M_PI / 180.0)) {
-        r.status = LGICP_PAIR_TRANSFORM;
-        continue;
-      }
-    }
-    const hm::Pose inv = hm::inverse(delta);
-    std::memcpy(r.delta_R, inv.R, sizeof(r.delta_R));
-    std::memcpy(r.delta_t, inv.t, sizeof(r.delta_t));
-    hm::quat_from_R(inv.R, r.delta_q);
-    double Ap[36];
-    {
-      int k = 3;
-      for (int a = 0; a < 6; ++a)
-        for (int b = a; b < 6; ++b) Ap[a * 6 + b] = Ap[b * 6 + a] = post[k++];
-    }
-    if (cfg.use_fixed_covariances) {
-      hm::fixed_covariance(cfg.laser_lc_rot_sigma, cfg.laser_lc_trans_sigma, r.covariance);
-      hm::inverse6(r.covariance, r.information);
-    } else if (cfg.covariance_method == LGICP_COV_POINT2POINT) {
-      hm::point_point_covariance(Ap /* = H */, r.fitness, r.covariance);
-      hm::inverse6(r.covariance, r.information);
-    } else {
-      hm::point_plane_covariance(Ap, cfg.laser_lc_rot_sigma, cfg.laser_lc_trans_sigma,
-                                 r.covariance);
-      for (int i = 0; i < 36; ++i) r.information[i] = Ap[i] / (0.05 * 0.05);
-    }
-    r.status = LGICP_PAIR_OK;
-    S.pairs_ok++;
-  }
+  finish_pairs(cfg, bp, h_pairs, h_state, h_ints, h_post, init_rejected, out, S);
   since("batch done");
   return LGICP_OK;
 }
