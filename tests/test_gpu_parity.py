@@ -146,7 +146,7 @@ def test_align_matches_oracle(ctx, n, seed, rd, tr):
     ang, tr_err = _rot_err(gn["T"], r["T"])
     assert ang < 1e-5 and tr_err < 1e-5, (ang, tr_err)
     assert r["iterations"] == gn["iterations"]
-    # reference solver (BFGS, stops at |grad| < 1e-2): measured gap, documented in DESIGN.md
+    # reference solver (BFGS, stops at |grad| < 1e-2): the two end within that tolerance of each other
     ang, tr_err = _rot_err(bf["T"], r["T"])
     assert ang < 1e-3 and tr_err < 1e-3, (ang, tr_err)
     fit, _ = O.fitness_score(src, tgt, r["T"])
