@@ -25,11 +25,18 @@ namespace lgicp {
 constexpr int FK_TILE = 64;
 constexpr int FK_STRIDE = 36;
 
+//
+// The targets are cut into gridDim.y ranges of `per_split` (a few hundred source descriptors
+// alone would leave most of the GPU idle): every range leaves its own k best per source
+// descriptor, ascending, in part_d / part_i [range][source][8]; feature_knn_merge_kernel folds
+// the ranges in ascending target order with the same strict `<`, which gives exactly what one
+// pass over all targets gives (lowest target index first among equal distances).
 __global__ __launch_bounds__(128) void feature_knn_kernel(const float* __restrict__ src_feat,
                                                           int n_src,
                                                           const float* __restrict__ tgt_feat,
-                                                          int n_tgt, int k,
-                                                          int* __restrict__ nn) {
+                                                          int n_tgt_all, int per_split, int k,
+                                                          float* __restrict__ part_d,
+                                                          int* __restrict__ part_i) {
   __shared__ __attribute__((aligned(16))) float tile[FK_TILE * FK_STRIDE];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float f[36];
@@ -39,7 +46,9 @@ __global__ __launch_bounds__(128) void feature_knn_kernel(const float* __restric
   int bi[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) bd[s] = __builtin_inff(), bi[s] = -1;
-  for (int j0 = 0; j0 < n_tgt; j0 += FK_TILE) {
+  const int j_begin = blockIdx.y * per_split;
+  const int n_tgt = min(n_tgt_all, j_begin + per_split);
+  for (int j0 = j_begin; j0 < n_tgt; j0 += FK_TILE) {
     __syncthreads();
     const int cnt = min(FK_TILE, n_tgt - j0);
     for (int e = threadIdx.x; e < cnt * 33; e += blockDim.x)
@@ -81,8 +90,42 @@ __global__ __launch_bounds__(128) void feature_knn_kernel(const float* __restric
       }
     }
   }
-  if (i < n_src)
-    for (int s = 0; s < k; ++s) nn[(size_t)i * k + s] = bi[s];
+  if (i < n_src) {
+    const size_t o = ((size_t)blockIdx.y * n_src + i) * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) part_d[o + s] = bd[s], part_i[o + s] = bi[s];
+  }
+}
+
+__global__ void feature_knn_merge_kernel(int n_src, int n_splits, int k,
+                                         const float* __restrict__ part_d,
+                                         const int* __restrict__ part_i, int* __restrict__ nn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_src) return;
+  float bd[8];
+  int bi[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bd[s] = __builtin_inff(), bi[s] = -1;
+  for (int r = 0; r < n_splits; ++r) {
+    const size_t o = ((size_t)r * n_src + i) * 8;
+    for (int e = 0; e < k; ++e) {
+      float cd = part_d[o + e];
+      int ci = part_i[o + e];
+      if (ci < 0) break;
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < k) {
+          const bool lt = cd < bd[s];
+          const float td = lt ? bd[s] : cd;
+          const int ti = lt ? bi[s] : ci;
+          bd[s] = lt ? cd : bd[s];
+          bi[s] = lt ? ci : bi[s];
+          cd = td;
+          ci = ti;
+        }
+    }
+  }
+  for (int s = 0; s < k; ++s) nn[(size_t)i * k + s] = bi[s];
 }
 
 // Scores hypotheses: workgroup (h, c) moves SS_QUERIES source keypoints (4 per lane) by
@@ -317,6 +360,27 @@ struct Scratch {
 };
 }  // namespace
 
+// descriptor k-NN table [n_src][k] (device pointers; partial lists live in `d`)
+static int launch_feature_knn(lgicp_ctx* ctx, Scratch& d, const float* d_sf, int n_src,
+                              const float* d_tf, int n_tgt, int k, int* d_nn, hipStream_t st) {
+  const int src_blocks = (n_src + 127) / 128;
+  // enough target ranges for ~4 workgroups per CU, each at least four tiles long
+  int n_splits = std::max(1, std::min((1024 + src_blocks - 1) / src_blocks,
+                                      (n_tgt + 4 * lgicp::FK_TILE - 1) / (4 * lgicp::FK_TILE)));
+  int per_split = (n_tgt + n_splits - 1) / n_splits;
+  per_split = ((per_split + lgicp::FK_TILE - 1) / lgicp::FK_TILE) * lgicp::FK_TILE;
+  n_splits = (n_tgt + per_split - 1) / per_split;
+  float* d_pd = d.alloc<float>((size_t)n_splits * n_src * 8);
+  int* d_pi = d.alloc<int>((size_t)n_splits * n_src * 8);
+  if (!d_pd || !d_pi) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  hipLaunchKernelGGL(lgicp::feature_knn_kernel, dim3(src_blocks, n_splits), dim3(128), 0, st, d_sf,
+                     n_src, d_tf, n_tgt, per_split, k, d_pd, d_pi);
+  hipLaunchKernelGGL(lgicp::feature_knn_merge_kernel, dim3((n_src + 127) / 128), dim3(128), 0, st,
+                     n_src, n_splits, k, d_pd, d_pi, d_nn);
+  HIP_TRY(ctx, hipGetLastError());
+  return LGICP_OK;
+}
+
 // SAC-IA on the keypoints/descriptors of two clouds.  score = getFitnessScore() of the
 // keypoint alignment, DBL_MAX when the source has fewer than 3 keypoints or the target none.
 int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
@@ -341,9 +405,10 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
   HIP_TRY(ctx, hipMemcpyAsync(d_tf, tgt.feat.data(), sizeof(float) * tgt.feat.size(), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_sk, hs.data(), sizeof(float4) * n_src, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_tk, ht.data(), sizeof(float4) * n_tgt, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(lgicp::feature_knn_kernel, dim3((n_src + 127) / 128), dim3(128), 0, st, d_sf,
-                     n_src, d_tf, n_tgt, k, d_nn);
-  HIP_TRY(ctx, hipGetLastError());
+  {
+    const int rc = launch_feature_knn(ctx, d, d_sf, n_src, d_tf, n_tgt, k, d_nn, st);
+    if (rc != LGICP_OK) return rc;
+  }
   std::vector<int> nn((size_t)n_src * k);
   HIP_TRY(ctx, hipMemcpyAsync(nn.data(), d_nn, sizeof(int) * nn.size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -390,9 +455,10 @@ static int feature_knn_table(lgicp_ctx* ctx, const CloudFeatures& src, const Clo
   if (!d_sf || !d_tf || !d_nn) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
   HIP_TRY(ctx, hipMemcpyAsync(d_sf, src.feat.data(), sizeof(float) * src.feat.size(), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_tf, tgt.feat.data(), sizeof(float) * tgt.feat.size(), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(lgicp::feature_knn_kernel, dim3((n_src + 127) / 128), dim3(128), 0, st, d_sf,
-                     n_src, d_tf, n_tgt, k, d_nn);
-  HIP_TRY(ctx, hipGetLastError());
+  {
+    const int rc = launch_feature_knn(ctx, d, d_sf, n_src, d_tf, n_tgt, k, d_nn, st);
+    if (rc != LGICP_OK) return rc;
+  }
   nn->resize((size_t)n_src * k);
   HIP_TRY(ctx, hipMemcpyAsync(nn->data(), d_nn, sizeof(int) * nn->size(), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
