@@ -50,8 +50,25 @@ def room_pair():
                 nn_d2_iter0=d0, cov_knn_src_first64=O.cov_knn(src, 20, 1e-3)[:64])
 
 
+def front_end():
+    """Rows around the alignment: normals, keyed-scan filters, Harris / FPFH / SAC-IA / TEASER++
+    initialisation on a 3000-point room pair."""
+    src, sn, tgt, tn, T = F.make_pair(3000, 4321, rot_deg=3.0, trans=0.3)
+    nrm, cur = O.compute_normals(src, 10)
+    vox, vox_n = O.voxel_grid(src, 0.35, sn)
+    keep = O.random_sample_indices(len(src), 700, 17)
+    T_sac, fit_sac, _ = O.sac_initial_alignment(src, sn, tgt, tn, harris_radius=0.3, iterations=60)
+    T_te, used, n_matches, n_clique = O.teaser_initial_alignment(src, sn, tgt, tn, harris_radius=0.3)
+    return dict(normals=nrm, curvature=cur, voxel_xyz=vox, voxel_normals=vox_n, sample_idx=keep,
+                sac_T=T_sac, sac_fitness=np.float64(fit_sac), teaser_T=T_te,
+                teaser_used=np.int32(used), teaser_matches=np.int32(n_matches),
+                teaser_clique=np.int32(n_clique),
+                observability=O.icp_observability(src, sn))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "front_end_3000.npz"), **front_end())
     np.savez_compressed(os.path.join(OUT, "corner_alignment.npz"), **corner_alignment())
     np.savez_compressed(os.path.join(OUT, "plane_ap.npz"), **plane_ap())
     np.savez_compressed(os.path.join(OUT, "room_pair_2000.npz"), **room_pair())
