@@ -25,6 +25,16 @@
 // targets per packed instruction.  As in the exhaustive kernel a lane tracks only the minimum of each group
 // of 8 targets and the first group that lowered it; the index is recovered afterwards, and the
 // rare exact tie between groups is resolved by a second walk.
+//
+// Certificates.  Late in the GICP loop the transformation barely moves and almost every query
+// keeps its match.  A sweep therefore also leaves, per query, the position it was made from and a
+// lower bound of the distance from there to every target other than the match: the second
+// smallest distance it evaluated, the gaps of the tiles it ruled out for the lane, and the
+// radius beyond which the wave looked at nothing.  In a later pass a query that has moved by
+// delta and measures d to its old match keeps that match for certain when
+// sqrt(d) + delta < bound (triangle inequality, with a margin far above the rounding of the
+// float distance); such lanes are answered at once and take no part in the sweep, which then
+// only visits the tiles the remaining lanes need -- none at all when every lane is certain.
 #include "lgicp_device.h"
 
 namespace lgicp {
@@ -58,6 +68,10 @@ __device__ __forceinline__ float wave_max_f(float v) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int GROUP = 8;  // targets whose minimum is tracked together
+// Tiles are selected up to this factor beyond the squared distance the sweep needs for an exact
+// answer: without it the lane with the largest best distance of a wave would get a certificate
+// with no margin at all, every time.
+constexpr float WIDEN = 2.25f;
 
 // tile coordinates are read through the constant address space: with wave-uniform addresses
 // the compiler fetches them with scalar loads and feeds them to the vector ALU as scalar
@@ -96,8 +110,12 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
     z = ((Tm[8] * p.x + Tm[9] * p.y) + Tm[10] * p.z) + Tm[11];
   }
   const bool finite = __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+  float4* const cert = P.cert;  // optional
   if (__ballot(finite) == 0) {  // nothing to look up
-    if (qi >= 0) P.keys[qi] = NNKEY_NONE;
+    if (qi >= 0) {
+      P.keys[qi] = NNKEY_NONE;
+      if (cert) cert[qi] = make_float4(x, y, z, 0.f);  // bound 0: never certain
+    }
     return;
   }
   // the patch's box over its finite queries
@@ -119,25 +137,55 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
   // upper bound of this pass's nearest distance.  Tiles that cannot reach it are then dropped by
   // the per-lane test before any of their points is looked at.  The seed's own tile always
   // passes that test, so the sweep re-finds the seed (or something at least as close) itself.
+  // need: the lane takes part in the sweep.  A lane whose certificate still holds is answered
+  // from it (kept) and only rides along.
+  bool need = finite;
+  nnkey_t kept = NNKEY_NONE;
   if (use_seed && finite) {
     const nnkey_t prev = P.keys[qi];
     const unsigned pi = (unsigned)(prev & 0xFFFFFFFFu);
-    if (prev != NNKEY_NONE && pi < (unsigned)TG.n) {
+    const bool matched = prev != NNKEY_NONE && pi < (unsigned)TG.n;
+    float d = __builtin_inff();
+    if (matched) {
       const float4 p = TG.xyz[pi];
       const float dx = x - p.x, dy = y - p.y, dz = z - p.z;
-      const float d = (dx * dx + dy * dy) + dz * dz;
+      d = (dx * dx + dy * dy) + dz * dz;
       if (d <= cap) bestd = d;  // false for NaN
     }
+    if (cert) {
+      // c.xyz: where the query stood when the bound c.w was established
+      const float4 c = cert[qi];
+      const float mx = x - c.x, my = y - c.y, mz = z - c.z;
+      const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
+      // the float distance arithmetic is off by a few 1e-7 relative; 1e-5 and an absolute 1e-6
+      // (squares far from underflow) leave two orders of magnitude to spare.  NaNs fail.
+      if (matched) {
+        const float reach = (__builtin_amdgcn_sqrtf(d) + moved) * 1.00001f + 1.0e-6f;
+        if (reach < c.w) need = false, kept = ((nnkey_t)__float_as_uint(d) << 32) | pi;
+      } else if (prev == NNKEY_NONE && !final_pass) {
+        // nothing within the cap last time and nothing can have come within it since
+        const float reach = (__builtin_amdgcn_sqrtf(cap) + moved) * 1.00001f + 1.0e-6f;
+        if (reach < c.w) need = false;
+      }
+    }
+  }
+  if (__ballot(need) == 0) {  // every lane is certain (or has no query)
+    if (qi >= 0) P.keys[qi] = kept;
+    return;
   }
   unsigned visited = 0;
-  // wave-uniform: max over finite lanes of bestd, refreshed after every round.  With every lane
-  // seeded the first round already reaches as far as any lane can need.
-  float worst = wave_max_nonneg(finite ? bestd : 0.f);
+  float second = __builtin_inff();  // lower bound of the evaluated distances other than the best
+  float ruled = __builtin_inff();   // smallest gap of a tile that was ruled out without a walk
+  // wave-uniform: max over the sweeping lanes of bestd, refreshed after every round.  With every
+  // lane seeded the first round already reaches as far as any lane can need.
+  float worst = wave_max_nonneg(need ? bestd : 0.f);
+  float wround = worst;  // the value of `worst` the current round's tile selection used
   float lo = -1.0f;
-  float hi = __builtin_fminf(worst < __builtin_inff() ? __builtin_fmaxf(r0sq, worst) : r0sq, cap);
+  float hi = __builtin_fminf(worst < __builtin_inff() ? __builtin_fmaxf(r0sq, worst * WIDEN) : r0sq, cap);
   const int n_steps = (n_tiles + 63) / 64;
 
   for (;;) {
+    wround = worst;
     // boxes of the next 64 tiles are fetched while the current 64 are being worked on
     float4 nb0 = make_float4(0.f, 0.f, 0.f, 0.f), nb1 = nb0;
     if (lane < n_tiles) nb0 = tmin[lane], nb1 = tmax[lane];
@@ -150,7 +198,7 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
       const float gy = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.y - qy1, qy0 - b1.y));
       const float gz = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.z - qz1, qz0 - b1.z));
       const float lb = (gx * gx + gy * gy) + gz * gz;
-      unsigned long long mask = __ballot(t < n_tiles && lb > lo && lb <= hi && lb <= worst);
+      unsigned long long mask = __ballot(t < n_tiles && lb > lo && lb <= hi && lb <= wround * WIDEN);
       while (mask) {
         const int b = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -162,7 +210,10 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
         const float hy = __builtin_fmaxf(0.f, __builtin_fmaxf(y0 - y, y - y1));
         const float hz = __builtin_fmaxf(0.f, __builtin_fmaxf(z0 - z, z - z1));
         const float gl = (hx * hx + hy * hy) + hz * hz;
-        if (__ballot(finite && gl <= bestd && gl <= cap) == 0) continue;
+        if (__ballot(need && gl <= bestd && gl <= cap) == 0) {
+          ruled = __builtin_fminf(ruled, gl);
+          continue;
+        }
         const int tile = step * 64 + b;
         cfloat* const tx = tiles + (size_t)tile * (4 * SI_TILE);
         cfloat* const ty = tx + SI_TILE;
@@ -181,6 +232,9 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
           // +inf and NaN distances (padding, overflow) never count
           // a seeded bound counts as reached by the first group that equals it
           const bool lower = m < bestd || (m == bestd && bgrp < 0);
+          // the loser of the comparison is a target other than the final match (a seeded bound
+          // that no group has reached yet is the match itself or shows up again later)
+          second = __builtin_fminf(second, lower ? (bgrp >= 0 ? bestd : __builtin_inff()) : m);
           tie = lower ? false : (tie || m == bestd);
           bestd = lower ? m : bestd;
           bgrp = lower ? tile * (SI_TILE / GROUP) + g : bgrp;
@@ -188,8 +242,8 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
         ++visited;
       }
     }
-    worst = wave_max_nonneg(finite ? bestd : 0.f);
-    if (hi >= cap || worst <= hi) break;
+    worst = wave_max_nonneg(need ? bestd : 0.f);
+    if (hi >= cap || worst * WIDEN <= hi) break;
     lo = hi;
     hi = __builtin_fminf(hi * 4.0f, cap);
     if (!(hi < 1.0e30f)) hi = cap;
@@ -201,13 +255,18 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
   int idx = 0x7FFFFFFF;
   if (finite && bgrp >= 0) {
     const size_t o = (size_t)(bgrp / (SI_TILE / GROUP)) * (4 * SI_TILE) + (bgrp % (SI_TILE / GROUP)) * GROUP;
+    int n_best = 0;
+    float others = __builtin_inff();
 #pragma unroll
     for (int j = 0; j < GROUP; ++j) {
       const float dx = x - tf[o + j], dy = y - tf[o + SI_TILE + j], dz = z - tf[o + 2 * SI_TILE + j];
       const float d = (dx * dx + dy * dy) + dz * dz;
       const int id = tidx[o + 3 * SI_TILE + j];
       idx = (d == bestd && id < idx) ? id : idx;
+      n_best += d == bestd;
+      others = d == bestd ? others : __builtin_fminf(others, d);
     }
+    second = __builtin_fminf(second, n_best > 1 ? bestd : others);
   }
   // Rare: another group holds a target at exactly the same distance.  Re-walk every tile that
   // can contain one and take the lowest index among the exact matches.
@@ -239,10 +298,23 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
     }
   }
 
-  if (qi >= 0)
-    P.keys[qi] = (finite && bgrp >= 0 && idx != 0x7FFFFFFF)
-                     ? (((nnkey_t)__float_as_uint(bestd) << 32) | (unsigned)idx)
-                     : NNKEY_NONE;
+  if (qi >= 0) {
+    const bool found = finite && bgrp >= 0 && idx != 0x7FFFFFFF;
+    if (need || !finite) {
+      P.keys[qi] = found ? (((nnkey_t)__float_as_uint(bestd) << 32) | (unsigned)idx) : NNKEY_NONE;
+      if (cert) {
+        // Every target other than the match was either evaluated (second), lies in a tile ruled
+        // out for this lane (ruled), or in a tile the wave never selected: those are farther
+        // from the whole patch than the round's radius or the round's largest best distance.
+        // Without a match the bound covers every target.
+        float lb = __builtin_fminf(__builtin_fminf(second, ruled), __builtin_fminf(hi, wround * WIDEN));
+        if (!found) lb = __builtin_fminf(lb, bestd);
+        cert[qi] = make_float4(x, y, z, finite ? __builtin_amdgcn_sqrtf(lb) * 0.99999f : 0.f);
+      }
+    } else {
+      P.keys[qi] = kept;
+    }
+  }
   // spread over NN_COUNTER_SLOTS addresses: one hot address would serialise every wave of the
   // launch in a single L2 channel
   if (counters && lane == 0)

@@ -714,7 +714,7 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
 
   // ---- device scratch ----------------------------------------------------------------------
   size_t pair_bytes = 0;
-  for (auto& p : bp.pairs) pair_bytes += (size_t)bp.clouds[p.src_cloud].n * 24 + 512;
+  for (auto& p : bp.pairs) pair_bytes += (size_t)bp.clouds[p.src_cloud].n * 40 + 768;
   HIP_TRY(ctx, W->arena.reserve(bp.bytes + pair_bytes + 4096));
   Arena ar{W};
 
@@ -744,6 +744,8 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     pd.n_tgt = bp.clouds[pp.tgt_cloud].n;
     pd.out = ar.take<float4>((size_t)pd.n_src);
     pd.keys = ar.take<nnkey_t>((size_t)pd.n_src);
+    // reserved[6] = 2: seeds but no certificates (diagnostics)
+    pd.cert = (ctx->nn_exhaustive || cfg.reserved[6] == 2) ? nullptr : ar.take<float4>((size_t)pd.n_src);
     std::memcpy(pd.guess, pp.guess, sizeof(pd.guess));
     max_src_n = std::max(max_src_n, pd.n_src);
     PairState& s = h_state[p];
@@ -912,6 +914,11 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
                                 hipMemcpyHostToDevice, st));
   }
   HIP_TRY(ctx, launch_guess_transform(d_clouds, d_pairs, n_pairs, max_src_n, st));
+  // a pair that never enters the loop gets no lookup before the final one: its certificates must
+  // read as "never certain" instead of whatever the arena held
+  for (int p = 0; p < n_pairs; ++p)
+    if (!h_state[p].active && h_pairs[p].cert)
+      HIP_TRY(ctx, hipMemsetAsync(h_pairs[p].cert, 0, sizeof(float4) * (size_t)h_pairs[p].n_src, st));
   HIP_TRY(ctx, hipEventRecord(ev_prep, st));
 
   // ---- GICP outer loop -----------------------------------------------------------------------
@@ -1108,6 +1115,19 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   };
   float ms = 0;
   lgicp_stats& S = W->stats;
+  if (trace_t) {  // kernel times of every outer iteration, in microseconds
+    std::string line = "lgicp trace: nn/reduce/solve us per iteration:";
+    char buf[64];
+    for (size_t k = 0; k < nn_ev.size(); ++k) {
+      float a = 0, b = 0, c = 0;
+      (void)hipEventElapsedTime(&a, nn_ev[k].first, nn_ev[k].second);
+      (void)hipEventElapsedTime(&b, red_ev[k].first, red_ev[k].second);
+      (void)hipEventElapsedTime(&c, sol_ev[k].first, sol_ev[k].second);
+      snprintf(buf, sizeof(buf), " %.0f/%.0f/%.0f", 1e3 * a, 1e3 * b, 1e3 * c);
+      line += buf;
+    }
+    fprintf(stderr, "%s\n", line.c_str());
+  }
   const double nn_loop_ms = sum_ms(nn_ev);
   (void)hipEventElapsedTime(&ms, ev_post0, ev_post1);
   const double nn_final_ms = ms;
@@ -1258,7 +1278,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
         default:
           for (int k = 0; k < 16; ++k) pp.guess[k] = (k % 5 == 0) ? 1.f : 0.f;
       }
-      pair_bytes += (size_t)bp.clouds[pp.src_cloud].n * 24 + 512;
+      pair_bytes += (size_t)bp.clouds[pp.src_cloud].n * 40 + 768;
       bp.pairs.push_back(pp);
     }
     if (!bp.pairs.empty()) plans.push_back(std::move(bp));

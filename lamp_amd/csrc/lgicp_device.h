@@ -63,6 +63,8 @@ struct PairDev {
   int scan2_cloud;  // un-accumulated target keyframe (normals of the POINT2PLANE covariance)
   float4* out;      // guess * source, n_src points
   nnkey_t* keys;    // n_src packed 1-NN results
+  float4* cert;     // optional, n_src: where each query stood at its last full lookup (x, y, z) and
+                    // a lower bound (w) of its distance from there to every target but its match
   float guess[16];
   int n_src;
   int n_tgt;

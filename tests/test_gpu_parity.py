@@ -567,6 +567,51 @@ def test_submit_exhaustive_and_pruned_agree():
         assert np.allclose(a["information"], b["information"], rtol=1e-12)
 
 
+def test_lookup_certificates_change_nothing():
+    """From the second lookup pass on, queries whose match is provably unchanged are answered
+    without a search.  With the certificates switched off (reserved[6] = 2), and with the
+    exhaustive kernel, a batch must produce the same bits in every result field - including
+    pairs with duplicated targets, points far from everything, partial overlap and a pair that
+    never enters the loop."""
+    from lamp_amd import capi
+    rng = np.random.default_rng(11)
+    clouds = []
+    for i in range(6):
+        src, sn, tgt, tn, _ = F.make_pair(6000 + 512 * i, 300 + i, rot_deg=1.0 + i, trans=0.1 + 0.08 * i)
+        tgt = tgt.copy()
+        tgt[1000:1100] = tgt[2000:2100]                  # exact duplicates: ties
+        src = src.copy()
+        src[:5] += 6.0                                   # nothing within the correspondence distance
+        if i == 4:
+            src[5000:] += (1.0, 0.0, 0.0)                # partial overlap
+        clouds.append((src, sn, tgt, tn))
+    tiny = rng.normal(size=(5, 3)).astype(np.float32)    # fewer points than k_correspondences
+    tiny_n = np.tile(np.float32([0, 0, 1]), (5, 1))
+    outs = []
+    for mode in ((0, 0), (0, 2), (1, 0)):
+        res = [0] * 8
+        res[2], res[6] = mode
+        c = capi.Context(init_method=capi.INIT_IDENTITY, reserved=(capi.C.c_int * 8)(*res))
+        try:
+            for i, (src, sn, tgt, tn) in enumerate(clouds):
+                _register(c, 100 + 10 * i, tgt, tn)
+                _register(c, 900 + 10 * i, src, sn)
+            _register(c, 5000, tiny, tiny_n)
+            pairs = [(900 + 10 * i, 100 + 10 * i) for i in range(6)] + [(5000, 100), (900, 110)]
+            outs.append([capi.result_to_dict(r) for r in c.submit(pairs)])
+        finally:
+            c.close()
+    assert sum(r["status"] == 0 for r in outs[0]) >= 5, [r["status"] for r in outs[0]]
+    assert max(r["iterations"] for r in outs[0]) >= 5       # the certificates had passes to act on
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
+            assert a["n_correspondences"] == b["n_correspondences"]
+            assert np.array_equal(a["T_icp"], b["T_icp"])
+            assert np.float64(a["fitness"]).tobytes() == np.float64(b["fitness"]).tobytes()
+            assert np.array_equal(np.asarray(a["covariance"]), np.asarray(b["covariance"]), equal_nan=True)
+
+
 # ------------------------------------------------------------------ normals, observability
 def test_compute_normals_matches_oracle(ctx):
     """lamp_utils::ComputeNormals (PointCloudUtils.h:38-62).  Pinned by the reference on the
