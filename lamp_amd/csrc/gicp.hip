@@ -220,11 +220,22 @@ __device__ __forceinline__ int sym12(int i, int j) {
   return i * 12 - (i * (i - 1)) / 2 + (j - i);
 }
 
+__device__ __forceinline__ double lane_value(double v, int l) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Called by all 64 lanes of a wave with the same x.  The three angles go to three lanes, so the
+// wave pays for one sincos instead of three in a row.
 __device__ void theta_of_x(const double x[6], double Th[12], double dTh[3][9], bool want_d) {
-  double sf, cf, st, ct, sp, cp;
-  sincos(x[3], &sf, &cf);
-  sincos(x[4], &st, &ct);
-  sincos(x[5], &sp, &cp);
+  const int l3 = (int)(threadIdx.x & 63) % 3;
+  double sv, cv;
+  sincos(l3 == 0 ? x[3] : (l3 == 1 ? x[4] : x[5]), &sv, &cv);
+  const double sf = lane_value(sv, 0), cf = lane_value(cv, 0);
+  const double st = lane_value(sv, 1), ct = lane_value(cv, 1);
+  const double sp = lane_value(sv, 2), cp = lane_value(cv, 2);
   // R = Rz(psi) Ry(theta) Rx(phi), row-major
   const double R[9] = {cp * ct, cp * st * sf - sp * cf, cp * st * cf + sp * sf,
                        sp * ct, sp * st * sf + cp * cf, sp * st * cf - cp * sf,
@@ -375,8 +386,8 @@ struct SolveLds {
   double Q[144];   // full symmetric 12 x 12
   double b[12];
   double s[12];    // Q d
-  double J[72];    // 12 x 6
-  double QJ[72];
+  double dR[27];   // derivatives of the 9 rotation entries of Theta wrt the three angles
+  double QJ[27];   // (Q dR^T): rows = rotation entries, columns = angles
   double H[36];
   double g[6];
 };
@@ -412,13 +423,28 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
   PairState& S = st[pair];
   if (!S.active) return;
   const int lane = threadIdx.x;
+  // history of the cycle test: one entry per lane, fetched while the slabs are being summed
+  const unsigned long long my_hist = S.Thash[lane & 15];
   {
+    // every slab value is requested before the first one is used (a loop with a run-time trip
+    // count waits for each load in turn: 16 memory latencies on the critical path of the iteration)
     const int nc = n_chunks[pair];
-    for (int i = lane; i < NSTAT; i += 64) {
-      double acc = 0;
-      for (int c = 0; c < nc; ++c) acc += partials[((size_t)pair * RED_MAX_CHUNKS + c) * NSTAT + i];
-      L.stat[i] = acc;
+    const double* const base = partials + (size_t)pair * RED_MAX_CHUNKS * NSTAT;
+    double v0[RED_MAX_CHUNKS], v1[RED_MAX_CHUNKS];
+    const bool second = lane + 64 < NSTAT;
+#pragma unroll
+    for (int c = 0; c < RED_MAX_CHUNKS; ++c) {
+      v0[c] = c < nc ? base[c * NSTAT + lane] : 0.0;
+      v1[c] = (c < nc && second) ? base[c * NSTAT + lane + 64] : 0.0;
     }
+    double a0 = 0, a1 = 0;
+#pragma unroll
+    for (int c = 0; c < RED_MAX_CHUNKS; ++c) {
+      a0 = c < nc ? a0 + v0[c] : a0;
+      a1 = c < nc ? a1 + v1[c] : a1;
+    }
+    L.stat[lane] = a0;
+    if (second) L.stat[lane + 64] = a1;
   }
   __syncthreads();
 
@@ -462,41 +488,61 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     x[0] = T[3];
     x[1] = T[7];
     x[2] = T[11];
-    x[3] = atan2((double)T[9], (double)T[10]);
-    x[4] = asin(-(double)T[8]);
-    x[5] = atan2((double)T[4], (double)T[0]);
+    {
+      // the two atan2 in two lanes, one call
+      const bool odd = lane & 1;
+      const double at = atan2(odd ? (double)T[4] : (double)T[9], odd ? (double)T[0] : (double)T[10]);
+      x[3] = lane_value(at, 0);
+      x[4] = asin(-(double)T[8]);
+      x[5] = lane_value(at, 1);
+    }
     double Th[12], dTh[3][9], g12[12];
     theta_of_x(x, Th, dTh, true);
     double f = quad_eval_wave(L, Theta0, qc, Th, g12, lane);
     for (int it = 0; it < sp.max_inner_iterations; ++it) {
+      // H = 2 J^T Q J and g = -J^T grad with J = dTheta/dx: the translation columns of J are unit
+      // vectors and its angle columns only touch the nine rotation entries, so the products
+      // against those columns reduce to entries of Q and to nine-term sums.  Every sum runs over
+      // the same terms in the same order as the dense 12-term version (whose other terms are
+      // exact zeros).
       __syncthreads();
-      for (int e = lane; e < 72; e += 64) {
-        const int r = e / 6, c = e % 6;
-        double v = 0.0;
-        if (c < 3)
-          v = (r == 9 + c) ? 1.0 : 0.0;
-        else if (r < 9)
-          v = dTh[c - 3][r];
-        L.J[e] = v;
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int e = 0; e < 9; ++e) L.dR[c * 9 + e] = dTh[c][e];
+        L.g[0] = -g12[9], L.g[1] = -g12[10], L.g[2] = -g12[11];
       }
       __syncthreads();
-      if (lane < 6) {
+      if (lane < 27) {  // QJ[e][c] = sum_e2 Q[e][e2] dR[c][e2]
+        const int e = lane / 3, c = lane % 3;
         double acc = 0;
-        for (int e = 0; e < 12; ++e) acc += L.J[e * 6 + lane] * g12[e];
-        L.g[lane] = -acc;
-      }
-      for (int e = lane; e < 72; e += 64) {
-        const int r = e / 6, c = e % 6;
+#pragma unroll
+        for (int e2 = 0; e2 < 9; ++e2) acc += L.Q[e * 12 + e2] * L.dR[c * 9 + e2];
+        L.QJ[lane] = acc;
+      } else if (lane < 36) {  // H[3 + i][j] = 2 sum_e dR[i][e] Q[e][9 + j]
+        const int i = (lane - 27) / 3, j = (lane - 27) % 3;
         double acc = 0;
-        for (int e2 = 0; e2 < 12; ++e2) acc += L.Q[r * 12 + e2] * L.J[e2 * 6 + c];
-        L.QJ[e] = acc;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc += L.dR[i * 9 + e] * L.Q[e * 12 + 9 + j];
+        L.H[(3 + i) * 6 + j] = 2.0 * acc;
+      } else if (lane < 39) {  // g[3 + i] = -sum_e dR[i][e] grad[e]
+        const int i = lane - 36;
+        double acc = 0;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc += L.dR[i * 9 + e] * g12[e];
+        L.g[3 + i] = -acc;
+      } else if (lane < 48) {  // H[i][j] = 2 Q[9 + i][9 + j]
+        const int i = (lane - 39) / 3, j = (lane - 39) % 3;
+        L.H[i * 6 + j] = 2.0 * (L.Q[(9 + i) * 12 + 9 + j] * 1.0);
       }
       __syncthreads();
-      if (lane < 36) {
-        const int c = lane / 6, c2 = lane % 6;
+      if (lane < 9) {  // H[3 + i][3 + j] = 2 sum_e dR[i][e] QJ[e][j]
+        const int i = lane / 3, j = lane % 3;
         double acc = 0;
-        for (int e = 0; e < 12; ++e) acc += L.J[e * 6 + c] * L.QJ[e * 6 + c2];
-        L.H[lane] = 2.0 * acc;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc += L.dR[i * 9 + e] * L.QJ[e * 3 + j];
+        L.H[(3 + i) * 6 + 3 + j] = 2.0 * acc;
       }
       __syncthreads();
       double dx[6];
@@ -550,10 +596,18 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     // reports NoProgress in the same spot).
     bool cycle = false;
     {
-      const unsigned long long h = hash_T(T);
+      // both hashes in one pass: even lanes hash T, odd lanes Tprev
+      float W[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) W[i] = (lane & 1) ? Tprev[i] : T[i];
+      const unsigned long long hv = hash_T(W);
+      const unsigned long long h =
+          ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(hv >> 32), 0) << 32) |
+          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)hv, 0);
+      h_prev = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(hv >> 32), 1) << 32) |
+               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)hv, 1);
       const int n_hist = it_out - 1 < 16 ? it_out - 1 : 16;
-      for (int k = 0; k < n_hist; ++k) cycle = cycle || (S.Thash[k] == h);
-      h_prev = hash_T(Tprev);
+      cycle = __ballot(lane < n_hist && my_hist == h) != 0;
     }
     if (it_out >= sp.max_iterations || delta < 1 || cycle) {
       converged = true;

@@ -1,6 +1,6 @@
 """The lookup certificates must not change a single bit of a submit's results: runs one workload
 with certificates (default) and without (reserved[6] = 2) and compares every result field."""
-import json, os, sys, time
+import hashlib, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from lamp_amd import capi
@@ -41,7 +41,8 @@ def main():
     a, ms_a, ev_a = run(work, 0, steps)
     b, ms_b, ev_b = run(work, 2, steps)
     diff = [i for i in range(len(a)) if a[i] != b[i]]
-    print(json.dumps({"config": config, "pairs": len(a), "differing_pairs": len(diff), "first": diff[:5],
+    sig = hashlib.sha1(b"".join(b"".join(x if isinstance(x, bytes) else str(x).encode() for x in r) for r in a)).hexdigest()
+    print(json.dumps({"config": config, "pairs": len(a), "differing_pairs": len(diff), "first": diff[:5], "signature": sig,
                       "ms_with_certificates": ms_a, "ms_without": ms_b,
                       "executed_evals_with": ev_a, "executed_evals_without": ev_b}), flush=True)
     sys.exit(1 if diff else 0)
