@@ -89,14 +89,27 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
   const int per = (n + bm.z - 1) / bm.z;
   const int i0 = bm.y * per;
   const int i1 = min(n, i0 + per);
-  for (int base = i0 + wave * 64; base < i1; base += RED_THREADS) {  // wave-uniform
+  // The matches of several rounds are fetched ahead: a round then waits for one memory latency
+  // (its gathers) instead of two in a row (match, then gathers).
+  constexpr int AHEAD = 4;
+  for (int gbase = i0 + wave * 64; gbase < i1; gbase += AHEAD * RED_THREADS) {  // wave-uniform
+   nnkey_t kahead[AHEAD];
+#pragma unroll
+   for (int r = 0; r < AHEAD; ++r) {
+     const int i = gbase + r * RED_THREADS + lane;
+     kahead[r] = i < i1 ? P.keys[i] : NNKEY_NONE;
+   }
+#pragma unroll
+   for (int r = 0; r < AHEAD; ++r) {
+    const int base = gbase + r * RED_THREADS;
+    if (base >= i1) break;
     const int i = base + lane;
     double av[RM_ROWS_A], bv[RM_ROWS_B];
 #pragma unroll
     for (int r = 0; r < RM_ROWS_A; ++r) av[r] = 0.0;
 #pragma unroll
     for (int c = 0; c < RM_ROWS_B; ++c) bv[c] = 0.0;
-    const nnkey_t key = i < i1 ? P.keys[i] : NNKEY_NONE;
+    const nnkey_t key = kahead[r];
     const float d2 = __uint_as_float((unsigned)(key >> 32));
     if (key != NNKEY_NONE && (double)d2 < corr_dist2) {  // gicp.hpp:483
       const int j = (int)(key & 0xFFFFFFFFu);
@@ -161,6 +174,7 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
     // the next round's stores must not overtake these reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+   }
   }
 
   // D[row][col] sits in lane (row & 3) * 16 + col, register row >> 2; each wave parks its D in
