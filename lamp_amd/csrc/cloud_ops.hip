@@ -21,6 +21,30 @@ hipError_t launch_pad_fill(float4* xyz, int n, int n_pad, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One 64-byte record per point: (x, y, z, 1) followed by the six unique covariance entries.  The
+// reduction gathers a matched target's point and covariance together; from two separate arrays
+// that is two to three cache lines per correspondence, from a record it is one.
+__global__ void pack_records_kernel(const float4* __restrict__ xyz, const double* __restrict__ cov6,
+                                    int n, float4* __restrict__ rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* c = cov6 + 6 * (size_t)i;
+  float4* r = rec + 4 * (size_t)i;
+  r[0] = xyz[i];
+  double2* rc = reinterpret_cast<double2*>(r + 1);
+  rc[0] = make_double2(c[0], c[1]);
+  rc[1] = make_double2(c[2], c[3]);
+  rc[2] = make_double2(c[4], c[5]);
+}
+
+hipError_t launch_pack_records(const float4* xyz, const double* cov6, int n, float4* rec,
+                               hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_records_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xyz, cov6, n, rec);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Plain copy, 16 bytes per lane.  Tables and results of a batch travel between pinned host
 // memory and the device through this kernel rather than through hipMemcpyAsync: the copy is then
 // one more kernel in the stream's order (the runtime's copy path was measured to block the

@@ -114,9 +114,11 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
     if (key != NNKEY_NONE && (double)d2 < corr_dist2) {  // gicp.hpp:483
       const int j = (int)(key & 0xFFFFFFFFu);
       const float4 pf = P.out[i];
-      const float4 qf = TC.xyz[j];
+      // the matched target's point and covariance sit in one 64-byte record: one cache line
+      const float4* const tr = TC.rec + 4 * (size_t)j;
+      const float4 qf = tr[0];
       const double* c1 = SC.cov + 6 * (size_t)i;
-      const double* c2 = TC.cov + 6 * (size_t)j;
+      const double* c2 = reinterpret_cast<const double*>(tr + 1);
       const double a00 = c1[0], a01 = c1[1], a02 = c1[2], a11 = c1[3], a12 = c1[4], a22 = c1[5];
       // RC = R * C1
       double RC[9];

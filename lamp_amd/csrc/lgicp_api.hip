@@ -109,6 +109,8 @@ int build_keyframe_derived(lgicp_ctx* ctx, Keyframe* kf) {
   if (n == 0) return LGICP_OK;
   HIP_TRY(ctx, hipMalloc((void**)&kf->d_cov, sizeof(double) * 6 * (size_t)n));
   HIP_TRY(ctx, launch_cov_from_normals(kf->d_nrm, n, kf->d_cov, ctx->stream));
+  HIP_TRY(ctx, hipMalloc((void**)&kf->d_rec, sizeof(float4) * 4 * (size_t)n));
+  HIP_TRY(ctx, launch_pack_records(kf->d_xyz, kf->d_cov, n, kf->d_rec, ctx->stream));
   kf->d_nrm_x = kf->d_nrm;
   if (kf->normals_missing) {  // ExtractNormals falls back to ComputeNormals (k = 10)
     HIP_TRY(ctx, hipMalloc((void**)&kf->d_nrm_x, sizeof(float4) * (size_t)n));
@@ -335,7 +337,7 @@ int plan_cloud(lgicp_ctx* ctx, BatchPlan& bp, uint64_t key, bool accumulate) {
   cp.n = ctx->scans.at(key).n;
   for (auto& s : cp.segs) cp.n += ctx->scans.at(s.first).n;
   cp.n_pad = std::max(NN_TILE, round_up(cp.n, NN_TILE));
-  if (acc || ctx->cfg.covariance_from_knn) bp.bytes += (size_t)cp.n * 48 + 256;  // covariances
+  if (acc || ctx->cfg.covariance_from_knn) bp.bytes += (size_t)cp.n * (48 + 64) + 512;  // covariances, records
   if (acc) {
     bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 32 + 1024;  // xyz + normals (+ estimated)
     // spatial index: tile-ordered points, boxes, visiting order
@@ -389,6 +391,7 @@ void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t
     cd.n_pad = cp.n_pad;
     const bool own_cov = cp.accumulated || cfg.covariance_from_knn;
     cd.cov = own_cov ? ar.take<double>((size_t)cp.n * 6) : kf.d_cov;
+    cd.rec = own_cov ? ar.take<float4>((size_t)cp.n * 4) : kf.d_rec;
     max_cloud_n = std::max(max_cloud_n, cp.n);
     if (!cp.accumulated) {
       cd.xyz = kf.d_xyz;
@@ -902,6 +905,10 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   }
   // covariances from normals and the NormalizePCloud constants were derived when the keyframes
   // were registered; accumulated clouds received their members' covariances in launch_assemble
+  for (int c = 0; c < n_clouds; ++c)
+    if (bp.clouds[c].accumulated || cfg.covariance_from_knn)
+      HIP_TRY(ctx, launch_pack_records(h_clouds[c].xyz, h_clouds[c].cov, h_clouds[c].n,
+                                       const_cast<float4*>(h_clouds[c].rec), st));
 
   // ---- FEATURES / TEASERPP initialisation -----------------------------------------------------
   std::vector<char> init_rejected((size_t)n_pairs, 0);

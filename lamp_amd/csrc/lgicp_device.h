@@ -40,6 +40,7 @@ struct CloudDev {
   const float4* nrm_x;  // lamp_utils::ExtractNormals of the cloud: nrm, or k-NN normals when the
                         // first stored normal is all zero (PointCloudUtils.cc:17-35)
   const double* cov;  // n x 6: c00 c01 c02 c11 c12 c22
+  const float4* rec;  // n records of 64 bytes: the point (x, y, z, 1), then the same six doubles
   int n;
   int n_pad;
   // spatial index (spatial_index.hip)
@@ -99,6 +100,8 @@ struct SolveParams {
 hipError_t launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t stream);
 hipError_t launch_pad_fill(float4* xyz, int n, int n_pad, hipStream_t stream);
 hipError_t launch_cov_from_normals(const float4* nrm, int n, double* cov6, hipStream_t stream);
+hipError_t launch_pack_records(const float4* xyz, const double* cov6, int n, float4* rec,
+                               hipStream_t stream);
 
 struct SegmentDev {  // one keyframe appended to an accumulated cloud
   const float4* src_xyz;

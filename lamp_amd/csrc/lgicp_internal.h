@@ -41,6 +41,7 @@ struct Keyframe {
   // derived once at registration: covariances from the normals (gicp_utils.h:28-62) and the
   // NormalizePCloud constants (PointCloudUtils.cc:39-59); both depend on the keyframe alone
   double* d_cov = nullptr;  // n x 6
+  float4* d_rec = nullptr;  // n x 64 bytes: point + covariance, what the reduction gathers per match
   // lamp_utils::ExtractNormals of the keyframe: d_nrm itself, or k-NN normals (own buffer) when
   // the first stored normal is all zero
   float4* d_nrm_x = nullptr;
@@ -50,12 +51,13 @@ struct Keyframe {
   void free_device() {
     if (d_nrm_x == d_nrm) d_nrm_x = nullptr;
     for (void* p : {(void*)d_xyz, (void*)d_nrm, (void*)d_order, (void*)d_sxyz, (void*)d_tmin,
-                    (void*)d_tmax, (void*)d_qorder, (void*)d_cov, (void*)d_nrm_x})
+                    (void*)d_tmax, (void*)d_qorder, (void*)d_cov, (void*)d_nrm_x, (void*)d_rec})
       if (p) (void)hipFree(p);
     d_nrm_x = nullptr;
     d_xyz = d_nrm = d_sxyz = d_tmin = d_tmax = nullptr;
     d_order = d_qorder = nullptr;
     d_cov = nullptr;
+    d_rec = nullptr;
   }
 };
 
