@@ -118,11 +118,6 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
     }
     return;
   }
-  // the patch's box over its finite queries
-  const float nanv = __builtin_nanf("");
-  const float fx = finite ? x : nanv, fy = finite ? y : nanv, fz = finite ? z : nanv;
-  const float qx0 = wave_min_f(fx), qy0 = wave_min_f(fy), qz0 = wave_min_f(fz);
-  const float qx1 = wave_max_f(fx), qy1 = wave_max_f(fy), qz1 = wave_max_f(fz);
   const v2f x2 = {x, x}, y2 = {y, y}, z2 = {z, z};
 
   const float4* __restrict__ tmin = TG.tmin;
@@ -173,6 +168,12 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
     if (qi >= 0) P.keys[qi] = kept;
     return;
   }
+  // the box of the queries that take part in the sweep: the whole patch in the first passes, a
+  // few scattered queries later on (tiles are then selected for those alone)
+  const float nanv = __builtin_nanf("");
+  const float fx = need ? x : nanv, fy = need ? y : nanv, fz = need ? z : nanv;
+  const float qx0 = wave_min_f(fx), qy0 = wave_min_f(fy), qz0 = wave_min_f(fz);
+  const float qx1 = wave_max_f(fx), qy1 = wave_max_f(fy), qz1 = wave_max_f(fz);
   unsigned visited = 0;
   float second = __builtin_inff();  // lower bound of the evaluated distances other than the best
   float ruled = __builtin_inff();   // smallest gap of a tile that was ruled out without a walk
@@ -181,7 +182,11 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
   float worst = wave_max_nonneg(need ? bestd : 0.f);
   float wround = worst;  // the value of `worst` the current round's tile selection used
   float lo = -1.0f;
-  float hi = __builtin_fminf(worst < __builtin_inff() ? __builtin_fmaxf(r0sq, worst * WIDEN) : r0sq, cap);
+  // tiles are looked at somewhat beyond the cap as well (their gaps only, never their points): a
+  // query with nothing inside the cap then learns how far away the nearest candidate tile is,
+  // and can be certain later on that still nothing has come within the cap
+  const float capsel = cap * WIDEN;
+  float hi = __builtin_fminf(worst < __builtin_inff() ? __builtin_fmaxf(r0sq, worst * WIDEN) : r0sq, capsel);
   const int n_steps = (n_tiles + 63) / 64;
 
   for (;;) {
@@ -243,10 +248,10 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
       }
     }
     worst = wave_max_nonneg(need ? bestd : 0.f);
-    if (hi >= cap || worst * WIDEN <= hi) break;
+    if (hi >= capsel || worst * WIDEN <= hi) break;
     lo = hi;
-    hi = __builtin_fminf(hi * 4.0f, cap);
-    if (!(hi < 1.0e30f)) hi = cap;
+    hi = __builtin_fminf(hi * 4.0f, capsel);
+    if (!(hi < 1.0e30f)) hi = capsel;
   }
 
   // lowest original index inside the winning group
