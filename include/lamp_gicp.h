@@ -108,7 +108,9 @@ typedef struct lgicp_config {
                                  [2] 1 = use the exhaustive 1-NN kernel instead of the pruned
                                  one; [3] first-round radius of the pruned search in mm;
                                  [5] 1 = host round trip after every outer iteration; [6] 1 = no
-                                 seeding of a lookup with the previous match; [7] parts of a
+                                 seeding of a lookup with the previous match, 2 = seeding but no
+                                 lookup certificates (every query searches in every pass; the
+                                 results are the same bits either way); [7] parts of a
                                  submit in flight at once (1..4, default 4) */
 } lgicp_config;
 
