@@ -220,22 +220,6 @@ hipError_t launch_gicp_reduce(const CloudDev* clouds, const PairDev* pairs, cons
 // ---------------------------------------------------------------------------------------------
 // Gauss-Newton on the quadratic form.  Theta index: 3*k + a, k = column (0..3), a = row.
 
-struct QuadForm {
-  double Q[78];  // symmetric 12x12, packed upper triangle (i <= j): i*12 - i*(i-1)/2 + (j-i)
-  double b[12];
-  double c;
-  double Theta0[12];
-};
-
-__device__ __forceinline__ int sym12(int i, int j) {
-  if (i > j) {
-    const int t = i;
-    i = j;
-    j = t;
-  }
-  return i * 12 - (i * (i - 1)) / 2 + (j - i);
-}
-
 __device__ __forceinline__ double lane_value(double v, int l) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
@@ -277,19 +261,6 @@ __device__ void theta_of_x(const double x[6], double Th[12], double dTh[3][9], b
         dTh[2][k * 3 + a] = dpsi[a * 3 + k];
       }
   }
-}
-
-__device__ double quad_eval(const QuadForm& q, const double Th[12], double* grad12) {
-  double d[12];
-  for (int i = 0; i < 12; ++i) d[i] = Th[i] - q.Theta0[i];
-  double f = q.c;
-  for (int i = 0; i < 12; ++i) {
-    double s = 0;
-    for (int j = 0; j < 12; ++j) s += q.Q[sym12(i, j)] * d[j];
-    f += d[i] * (2.0 * q.b[i] + s);
-    if (grad12) grad12[i] = 2.0 * (q.b[i] + s);
-  }
-  return f;
 }
 
 // Solves H dx = g by Cholesky (H symmetric 6x6, lower triangle read).  Every loop has constant

@@ -815,7 +815,6 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
     evals_per_pass += (double)pd.n_src * (double)pd.n_tgt;
   }
   build_maps(all_pairs);
-  const size_t off_done = (size_t)n_pairs;  // n_done, then one "active" flag per pair
 
   // ---- one upload -----------------------------------------------------------------------------
   // Every host-built table goes through one pinned staging buffer and one copy; the live 1-NN
@@ -941,7 +940,6 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   std::memset(h_live, 0, sizeof(int) * ((size_t)n_pairs + 1));
   int* d_done = nullptr;
   HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_done, h_live, 0));
-  (void)off_done;
   // One 1-NN pass over the pairs of the current block map.  Inside the GICP loop only matches
   // closer than the correspondence threshold are used (gicp.hpp:476), so the pruned search is
   // capped just above it; the pass after the loop is exact for every point.

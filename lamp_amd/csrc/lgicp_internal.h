@@ -86,9 +86,9 @@ struct DevBuf {  // grow-only device array
 using namespace lgicp_detail;
 
 // Everything one in-flight batch needs on the device and for talking to it.  A context owns
-// several of these so that parts of a submit can be in flight at once: while one half sits in
+// several of these so that parts of a submit can be in flight at once: while one part sits in
 // a latency-bound stretch (the 6x6 solves, the last stragglers of the outer loop, host
-// bookkeeping) the other half's bulk kernels keep the GPU busy.
+// bookkeeping) the other parts' bulk kernels keep the GPU busy.
 struct BatchSlot {
   hipStream_t stream = nullptr;
   DevBuf<char> arena;                 // per-batch scratch (bump allocated)
