@@ -490,14 +490,27 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
                              std::vector<char>& init_rejected) {
   const lgicp_config& cfg = ctx->cfg;
   const int n_pairs = (int)bp.pairs.size();
-  std::map<int, CloudFeatures> feats;
+  std::map<int, std::shared_ptr<CloudFeatures>> feat_ptr;
   for (int p = 0; p < n_pairs; ++p)
     for (int c : {bp.pairs[p].src_cloud, bp.pairs[p].tgt_cloud})
-      if (!feats.count(c)) {
-        const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm_x,
-                                              h_clouds[c].n, &feats[c]);
-        if (rc != LGICP_OK) return rc;
+      if (!feat_ptr.count(c)) {
+        // a keyframe on its own keeps its features for later submits; an accumulated cloud is
+        // assembled per batch and so are its features
+        Keyframe& kf = ctx->scans.at(bp.clouds[c].key);
+        std::shared_ptr<CloudFeatures> f = bp.clouds[c].accumulated ? nullptr : kf.features;
+        if (!f) {
+          f = std::make_shared<CloudFeatures>();
+          const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm_x,
+                                                h_clouds[c].n, f.get());
+          if (rc != LGICP_OK) return rc;
+          if (!bp.clouds[c].accumulated) kf.features = f;
+        }
+        feat_ptr[c] = f;
       }
+  struct FeatView {  // feats[c] as before
+    std::map<int, std::shared_ptr<CloudFeatures>>& m;
+    const CloudFeatures& operator[](int c) const { return *m.at(c); }
+  } feats{feat_ptr};
   if (cfg.init_method == LGICP_INIT_TEASERPP) {
     // IcpLoopComputation.cc:528-531: never rejects; keeps the odometry guess unless the
     // TEASER++ transform explains the descriptor matches at least as well.  The matches and

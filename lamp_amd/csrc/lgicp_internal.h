@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -24,6 +25,8 @@ using namespace lgicp;
 namespace lgicp_detail {
 
 inline std::string g_create_error;
+
+struct CloudFeatures;
 
 struct Keyframe {
   int n = 0;
@@ -48,6 +51,10 @@ struct Keyframe {
   bool normals_missing = false;
   float centroid[3] = {0.f, 0.f, 0.f};
   float factor = 0.f;
+  // Harris keypoints and FPFH descriptors of the keyframe on its own, computed by the first
+  // FEATURES / TEASERPP submit that needs them (they depend on the keyframe and the context's
+  // parameters alone, and a keyframe shows up in many candidates over its lifetime)
+  std::shared_ptr<CloudFeatures> features;
   void free_device() {
     if (d_nrm_x == d_nrm) d_nrm_x = nullptr;
     for (void* p : {(void*)d_xyz, (void*)d_nrm, (void*)d_order, (void*)d_sxyz, (void*)d_tmin,

@@ -420,6 +420,23 @@ def test_submit_features_init_matches_oracle():
             assert d["converged"] == ref["converged"]
             ang, te = _rot_err(ref["T"], d["T_icp"])
             assert ang < 1e-4 and te < 1e-4
+        # keyframes keep their keypoints and descriptors between submits: same bits again, also
+        # for a pair that meets two already-seen keyframes in a new combination
+        again = c.submit([(k[0], k[1]) for k in cases])
+        for a, b in zip(res, again):
+            assert bytes(a) == bytes(b)
+        first = capi.result_to_dict(c.submit([(cases[0][0], cases[1][1])])[0])
+        c2 = capi.Context(init_method=capi.INIT_FEATURES, harris_radius=radius, sac_iterations=100,
+                          transform_thresholding=0)
+        try:
+            _register(c2, cases[1][1], cases[1][4], cases[1][5])
+            _register(c2, cases[0][0], cases[0][2], cases[0][3], t=(0.05, 0.0, 0.0))
+            fresh = capi.result_to_dict(c2.submit([(cases[0][0], cases[1][1])])[0])
+        finally:
+            c2.close()
+        assert first["status"] == fresh["status"]
+        assert np.array_equal(first["T_init"], fresh["T_init"])
+        assert first["init_fitness"] == fresh["init_fitness"]
     finally:
         c.close()
     # threshold below every achievable score: all pairs are dropped at the initialisation
