@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--nn-variant", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the result gather even with one rank")
+    ap.add_argument("--slots", type=int, default=0,
+                    help="parts of a submit in flight at once (0 = the library's default)")
     ap.add_argument("--exhaustive", action="store_true",
                     help="use the exhaustive 1-NN kernel instead of the pruned one")
     args = ap.parse_args()
@@ -107,6 +109,8 @@ def main():
         cfg.reserved[0] = args.nn_variant
     if args.exhaustive:
         cfg.reserved[2] = 1
+    if args.slots:
+        cfg.reserved[7] = args.slots
     ctx = capi.Context(cfg)
     work.register(ctx)                      # keyframes + poses resident in HBM before timing
     cands = work.candidates()

@@ -21,6 +21,20 @@ hipError_t launch_pad_fill(float4* xyz, int n, int n_pad, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One wave that stays on the GPU for a given time (constant 100 MHz clock) and does nothing.
+// Two of them on two streams finish together when the streams feed different hardware queues
+// and one after the other when they share one: that is how the library tells them apart.
+__global__ void delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+hipError_t launch_delay(double microseconds, hipStream_t stream) {
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, stream, (long long)(microseconds * 100.0));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // One 64-byte record per point: (x, y, z, 1) followed by the six unique covariance entries.  The
 // reduction gathers a matched target's point and covariance together; from two separate arrays
 // that is two to three cache lines per correspondence, from a record it is one.

@@ -99,6 +99,8 @@ struct SolveParams {
 // dst/src 16-byte aligned, both readable/writable up to the next multiple of 16 bytes
 hipError_t launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t stream);
 hipError_t launch_pad_fill(float4* xyz, int n, int n_pad, hipStream_t stream);
+// one idle wave that occupies `stream` for the given time
+hipError_t launch_delay(double microseconds, hipStream_t stream);
 hipError_t launch_cov_from_normals(const float4* nrm, int n, double* cov6, hipStream_t stream);
 hipError_t launch_pack_records(const float4* xyz, const double* cov6, int n, float4* rec,
                                hipStream_t stream);

@@ -126,8 +126,10 @@ struct BatchSlot {
     }
     return ev_pool[ev_used++];
   }
-  bool create() {
-    return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+  // takes ownership of `s`
+  bool create(hipStream_t s) {
+    stream = s;
+    return s != nullptr &&
            hipHostMalloc((void**)&h_done, sizeof(int) * 65536, hipHostMallocDefault) == hipSuccess;
   }
   void destroy() {

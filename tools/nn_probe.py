@@ -9,6 +9,18 @@ def main():
     for a in sys.argv[1:]:
         k, v = a.split("=")
         kw[k] = int(v)
+    with_torch = kw.pop("torch", 0)   # 1: import torch and touch the GPU first; 2: also a process group
+    if with_torch:
+        import torch
+        torch.cuda.set_device(0)
+        torch.zeros(1, device="cuda")
+        if with_torch >= 2:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            if with_torch >= 3:
+                t = torch.zeros(8, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+    print("hip runtimes:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l or "librccl" in l or "libhsa-runtime" in l}), flush=True)
     res = [0] * 8
     res[2] = kw.pop("exhaustive", 0)
     res[3] = kw.pop("r0mm", 0)
