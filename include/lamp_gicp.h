@@ -111,7 +111,8 @@ typedef struct lgicp_config {
                                  seeding of a lookup with the previous match, 2 = seeding but no
                                  lookup certificates (every query searches in every pass; the
                                  results are the same bits either way); [7] parts of a
-                                 submit in flight at once (1..4, default 4) */
+                                 submit in flight at once (1..4; default: up to 4, as many as
+                                 streams were found whose kernels overlap) */
 } lgicp_config;
 
 /* pose_graph_msgs/LoopCandidate (pose_graph_msgs/msg/LoopCandidate.msg:1-18) */

@@ -143,7 +143,9 @@ namespace {
 // per C2 submit inside a process that had merely imported another GPU library first).  So
 // streams are created one by one and a new one is kept only if an idle wave on it overlaps an
 // idle wave on every stream kept so far.
-std::vector<hipStream_t> concurrent_streams(int wanted) {
+// probe = false: `wanted` streams as the runtime hands them out (an explicit request, e.g. under a
+// profiler that serialises all kernels, where nothing overlaps and the test would keep one stream).
+std::vector<hipStream_t> concurrent_streams(int wanted, bool probe) {
   std::vector<hipStream_t> kept, spare;
   auto fresh = []() -> hipStream_t {
     hipStream_t s = nullptr;
@@ -153,6 +155,14 @@ std::vector<hipStream_t> concurrent_streams(int wanted) {
   if (!first) return kept;
   kept.push_back(first);
   if (wanted <= 1) return kept;
+  if (!probe) {
+    while ((int)kept.size() < wanted) {
+      hipStream_t s = fresh();
+      if (!s) break;
+      kept.push_back(s);
+    }
+    return kept;
+  }
   constexpr double kDelayUs = 150.0;
   (void)launch_delay(1.0, first);  // loads the kernel
   (void)hipStreamSynchronize(first);
@@ -253,7 +263,7 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
   }
   if (cfg->reserved[7] >= 1 && cfg->reserved[7] <= lgicp_ctx::MAX_SLOTS)
     ctx->n_slots = cfg->reserved[7];
-  std::vector<hipStream_t> streams = concurrent_streams(ctx->n_slots);
+  std::vector<hipStream_t> streams = concurrent_streams(ctx->n_slots, /*probe=*/cfg->reserved[7] < 1);
   ctx->n_slots = std::max<int>(1, std::min<int>(ctx->n_slots, (int)streams.size()));
   bool slots_ok = !streams.empty();
   for (int k = 0; k < ctx->n_slots && slots_ok; ++k) slots_ok = ctx->slot[k].create(streams[k]);
