@@ -20,7 +20,8 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
             if with_torch >= 3:
                 t = torch.zeros(8, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
-    print("hip runtimes:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l or "librccl" in l or "libhsa-runtime" in l}), flush=True)
+    if with_torch:
+        print("hip runtimes:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l or "librccl" in l or "libhsa-runtime" in l}), flush=True)
     res = [0] * 8
     res[2] = kw.pop("exhaustive", 0)
     res[3] = kw.pop("r0mm", 0)
