@@ -10,7 +10,8 @@
 // k-d partition order cut into tiles of SI_TILE points, each point stored with its original index,
 // plus the axis-aligned box of every tile and the same visiting order of the cloud's own
 // points.  One wave owns 64 consecutive queries of that order — a compact patch of surface — and keeps
-// the patch's box.  The float box-to-box gap, squared and summed in the same operation order as
+// the box of those of them that still search (all of them in the first passes, see
+// "Certificates").  The float box-to-box gap, squared and summed in the same operation order as
 // a point distance, never exceeds the computed distance of any query/target pair drawn from
 // the two boxes (rounding is monotonic), so a tile whose gap exceeds every lane's current best
 // cannot improve or tie any lane and is skipped without touching its points.
