@@ -632,7 +632,15 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     std::vector<std::thread> pool;
     for (int j = 0; j < window; ++j) pool.emplace_back(worker);
     int rc_prepare = LGICP_OK;
-    for (int p = 0; p < n_pairs && rc_prepare == LGICP_OK; ++p) {
+    // largest first: the host half of a pair grows steeply with its number of matches (five per
+    // source keypoint), and the submit ends when the slowest pair does
+    std::vector<int> by_size((size_t)n_pairs);
+    for (int p = 0; p < n_pairs; ++p) by_size[p] = p;
+    std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) {
+      return feats[bp.pairs[a].src_cloud].idx.size() > feats[bp.pairs[b].src_cloud].idx.size();
+    });
+    for (int q = 0; q < n_pairs && rc_prepare == LGICP_OK; ++q) {
+      const int p = by_size[q];
       int j;
       {
         std::unique_lock<std::mutex> lk(mu);
