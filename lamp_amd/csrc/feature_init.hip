@@ -610,7 +610,10 @@ int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], f
   const tz::Params prm;
   bool device_ok = true;
   const tz::Solution sol = tz::solve_on_clique(
-      job.src, job.dst, tz::greedy_clique(job.graph), prm,
+      job.src, job.dst,
+      // large graphs: a pair with ten thousand matches would otherwise keep one thread busy for
+      // hundreds of milliseconds after every other pair of the submit has finished
+      tz::greedy_clique(job.graph, job.graph.n >= 2048 ? 8 : 1), prm,
       [&](const std::vector<double>& cs, const std::vector<double>& cd, const tz::Params& p, double R[9]) {
         if (cs.size() / 3 < 128)
           tz::clique_rotation_host(cs, cd, p, R);

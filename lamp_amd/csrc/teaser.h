@@ -11,9 +11,13 @@
 #pragma once
 
 #include <algorithm>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace lgicp {
@@ -77,8 +81,15 @@ inline std::vector<int> core_bounds(const BitGraph& g) {
 }
 
 // Greedy clique heuristic: vertices in order of decreasing bound (ascending id among equals);
-// from each, repeatedly move to the common neighbour with the largest (bound, id).
-inline std::vector<int> greedy_clique(const BitGraph& g) {
+// from each, repeatedly move to the common neighbour with the largest (bound, id).  A start
+// only looks at vertices whose bound exceeds the best size so far, so what it finds depends on
+// that size; the definition is the serial one: starts in order, each seeing the best size its
+// predecessors left.  With threads > 1 a window of starts is evaluated side by side against the
+// size at the window's beginning; as long as none of them improves it - the rule once the first
+// few starts have found a large clique - their results are exactly the serial ones, and when one
+// does, the starts after it in the window are repeated with the new size.  Same clique, bit for
+// bit, for any number of threads.
+inline std::vector<int> greedy_clique(const BitGraph& g, int threads = 1) {
   const int n = g.n;
   std::vector<int> best;
   if (n <= 0) return best;
@@ -91,11 +102,10 @@ inline std::vector<int> greedy_clique(const BitGraph& g) {
   std::vector<int> pref(n);
   for (int i = 0; i < n; ++i) pref[i] = i;
   std::sort(pref.begin(), pref.end(), [&](int a, int b) { return K[a] != K[b] ? K[a] > K[b] : a > b; });
-  int mc = 0;
-  std::vector<uint64_t> cand(g.words);
-  std::vector<int> C;
-  for (int v : order) {
-    if (K[v] <= mc) continue;
+  // one start: the clique found from v (without v) when the best size so far is mc; empty when
+  // v has too few eligible neighbours to beat it.  A pure function of its arguments.
+  auto start_from = [&](int v, int mc, std::vector<uint64_t>& cand, std::vector<int>& C) {
+    C.clear();
     int np = 0;
     for (int w = 0; w < g.words; ++w) {
       uint64_t m = g.row(v)[w], keep = 0;
@@ -106,8 +116,7 @@ inline std::vector<int> greedy_clique(const BitGraph& g) {
       }
       cand[w] = keep;
     }
-    if (np <= mc) continue;
-    C.clear();
+    if (np <= mc) return;
     for (int at = 0; at < n; ++at) {
       const int u = pref[at];
       if (!((cand[u >> 6] >> (u & 63)) & 1)) continue;
@@ -115,11 +124,94 @@ inline std::vector<int> greedy_clique(const BitGraph& g) {
       const uint64_t* r = g.row(u);
       for (int w = 0; w < g.words; ++w) cand[w] &= r[w];
     }
-    if ((int)C.size() + 1 > mc) {
-      mc = (int)C.size() + 1;
-      best = C;
-      best.push_back(v);
+  };
+  int mc = 0;
+  auto apply = [&](int v, const std::vector<int>& C) {
+    if (C.empty() || (int)C.size() + 1 <= mc) return false;
+    mc = (int)C.size() + 1;
+    best = C;
+    best.push_back(v);
+    return true;
+  };
+  // helpers for this call: at most threads - 1, and at most 16 over all calls running at once
+  // (several pairs of a submit are solved side by side)
+  static std::atomic<int> helpers_out{0};
+  int n_helpers = 0;
+  if (threads > 1) {
+    const int want = threads - 1;
+    const int before = helpers_out.fetch_add(want);
+    n_helpers = std::max(0, std::min(want, 16 - before));
+    helpers_out.fetch_sub(want - n_helpers);
+  }
+  const size_t cap = (size_t)(n_helpers + 1) * (n_helpers ? 16 : 1);  // starts per window
+  std::vector<int> window;
+  std::vector<std::vector<int>> found(cap);
+  std::vector<uint64_t> cand0((size_t)g.words);
+  // window state shared with the helpers
+  std::mutex mu;
+  std::condition_variable cv;
+  unsigned long generation = 0;
+  bool stop = false;
+  int mc0 = 0;
+  std::atomic<size_t> next{0}, done{0};
+  auto drain = [&](std::vector<uint64_t>& cand) {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= window.size()) return;
+      start_from(window[k], mc0, cand, found[k]);
+      done.fetch_add(1);
     }
+  };
+  std::vector<std::thread> pool;
+  for (int h = 0; h < n_helpers; ++h)
+    pool.emplace_back([&] {
+      std::vector<uint64_t> cand((size_t)g.words);
+      unsigned long seen = 0;
+      for (;;) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || generation != seen; });
+          if (stop) return;
+          seen = generation;
+        }
+        drain(cand);
+      }
+    });
+  int at = 0;
+  while (at < n) {
+    window.clear();
+    while (at < n && window.size() < cap) {
+      const int v = order[at++];
+      if (K[v] > mc) window.push_back(v);
+    }
+    if (window.empty()) break;
+    mc0 = mc;
+    next.store(0), done.store(0);
+    if (n_helpers) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        ++generation;
+      }
+      cv.notify_all();
+    }
+    drain(cand0);
+    while (done.load() < window.size()) std::this_thread::yield();
+    for (size_t k = 0; k < window.size(); ++k) {
+      if (mc != mc0) {  // an earlier start of this window raised the size: this one saw a stale one
+        if (K[window[k]] <= mc) continue;
+        start_from(window[k], mc, cand0, found[k]);
+      }
+      apply(window[k], found[k]);
+    }
+  }
+  if (n_helpers) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (std::thread& t : pool) t.join();
+    helpers_out.fetch_sub(n_helpers);
   }
   std::sort(best.begin(), best.end());
   return best;
