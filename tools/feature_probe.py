@@ -18,9 +18,11 @@ def main():
         out = c.submit_packed(packed)
         dt = time.time() - t
         st = [out[i].status for i in range(n_pairs)]
+        import hashlib
+        sig = hashlib.sha1(b"".join(bytes(out[i]) for i in range(n_pairs))).hexdigest()
         print(json.dumps({"rep": rep, "wall_ms": 1e3 * dt, "ms_per_pair": 1e3 * dt / n_pairs,
                           "ok": sum(s == 0 for s in st), "rejected": sum(s == capi.PAIR_INIT_REJECTED for s in st),
-                          "total_ms": c.stats().total_ms}), flush=True)
+                          "total_ms": c.stats().total_ms, "signature": sig}), flush=True)
     c.close()
 
 main()
