@@ -188,6 +188,8 @@ std::vector<hipStream_t> concurrent_streams(int wanted, bool probe) {
     (ok ? kept : spare).push_back(s);
   }
   for (hipStream_t s : spare) (void)hipStreamDestroy(s);
+  if (std::getenv("LGICP_TRACE"))
+    fprintf(stderr, "[lgicp] streams: %zu kept of %zu created\n", kept.size(), kept.size() + spare.size());
   return kept;
 }
 
