@@ -13,7 +13,7 @@ def main():
     c = capi.Context(init_method=method, harris_radius=radius, transform_thresholding=0)
     wl.register(c)
     packed = c.pack_candidates(wl.candidates())
-    for rep in range(3):
+    for rep in range(int(kw.get("reps", 3))):
         t = time.time()
         out = c.submit_packed(packed)
         dt = time.time() - t
