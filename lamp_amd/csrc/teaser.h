@@ -122,7 +122,14 @@ inline std::vector<int> greedy_clique(const BitGraph& g, int threads = 1) {
       if (!((cand[u >> 6] >> (u & 63)) & 1)) continue;
       C.push_back(u);
       const uint64_t* r = g.row(u);
-      for (int w = 0; w < g.words; ++w) cand[w] &= r[w];
+      int left = 0;
+      for (int w = 0; w < g.words; ++w) {
+        cand[w] &= r[w];
+        left += __builtin_popcountll(cand[w]);
+      }
+      // v, the vertices taken so far and every remaining candidate together cannot beat mc:
+      // whatever this start ends with would be discarded
+      if (1 + (int)C.size() + left <= mc) return;
     }
   };
   int mc = 0;
