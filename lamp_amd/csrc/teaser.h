@@ -154,11 +154,14 @@ inline std::vector<int> greedy_clique(const BitGraph& g, int threads = 1) {
   std::vector<int> window;
   std::vector<std::vector<int>> found(cap);
   std::vector<uint64_t> cand0((size_t)g.words);
-  // window state shared with the helpers
+  // Window state shared with the helpers.  A helper may only work on a window between the moment
+  // the main thread opens it and the moment it closes it again (both under the mutex, the latter
+  // only once no helper is inside): the window's vectors and counters are rewritten in between.
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv, cv_done;
   unsigned long generation = 0;
-  bool stop = false;
+  bool stop = false, open = false;
+  int inside = 0;
   int mc0 = 0;
   std::atomic<size_t> next{0}, done{0};
   auto drain = [&](std::vector<uint64_t>& cand) {
@@ -177,11 +180,17 @@ inline std::vector<int> greedy_clique(const BitGraph& g, int threads = 1) {
       for (;;) {
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return stop || generation != seen; });
+          cv.wait(lk, [&] { return stop || (open && generation != seen); });
           if (stop) return;
           seen = generation;
+          ++inside;
         }
         drain(cand);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          --inside;
+        }
+        cv_done.notify_all();
       }
     });
   int at = 0;
@@ -198,11 +207,16 @@ inline std::vector<int> greedy_clique(const BitGraph& g, int threads = 1) {
       {
         std::lock_guard<std::mutex> lk(mu);
         ++generation;
+        open = true;
       }
       cv.notify_all();
     }
     drain(cand0);
-    while (done.load() < window.size()) std::this_thread::yield();
+    if (n_helpers) {  // sleep, do not spin: the machine's cores are shared with the other pairs' threads
+      std::unique_lock<std::mutex> lk(mu);
+      cv_done.wait(lk, [&] { return inside == 0 && done.load() >= window.size(); });
+      open = false;
+    }
     for (size_t k = 0; k < window.size(); ++k) {
       if (mc != mc0) {  // an earlier start of this window raised the size: this one saw a stale one
         if (K[window[k]] <= mc) continue;
