@@ -163,22 +163,35 @@ std::vector<hipStream_t> concurrent_streams(int wanted, bool probe) {
     }
     return kept;
   }
-  constexpr double kDelayUs = 150.0;
+  constexpr double kDelayUs = 200.0;
   (void)launch_delay(1.0, first);  // loads the kernel
   (void)hipStreamSynchronize(first);
+  hipEvent_t e0 = nullptr, a_end = nullptr, b_start = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&a_end) != hipSuccess ||
+      hipEventCreate(&b_start) != hipSuccess)
+    return kept;
+  // Device timestamps, not host clocks: on a shared queue the marker that opens b's work waits
+  // behind a's idle wave, on separate queues it passes at once.  A host thread that loses the CPU
+  // between the two launches can only make separate queues look shared, so a few attempts are
+  // made and one overlap settles it.
   auto overlap = [&](hipStream_t a, hipStream_t b) {
-    double best = 1e30;
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < 4; ++rep) {
       (void)hipStreamSynchronize(a);
       (void)hipStreamSynchronize(b);
-      const auto t0 = std::chrono::steady_clock::now();
+      (void)hipEventRecord(e0, a);
       (void)launch_delay(kDelayUs, a);
+      (void)hipEventRecord(a_end, a);
+      (void)hipEventRecord(b_start, b);
       (void)launch_delay(kDelayUs, b);
       (void)hipStreamSynchronize(a);
       (void)hipStreamSynchronize(b);
-      best = std::min(best, 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+      float t_a_end = 0.f, t_b_start = 0.f;
+      if (hipEventElapsedTime(&t_a_end, e0, a_end) != hipSuccess ||
+          hipEventElapsedTime(&t_b_start, e0, b_start) != hipSuccess)
+        continue;
+      if (t_b_start < 0.5f * t_a_end) return true;
     }
-    return best < 1.6 * kDelayUs;
+    return false;
   };
   for (int tries = 0; tries < 4 * wanted && (int)kept.size() < wanted; ++tries) {
     hipStream_t s = fresh();
@@ -188,6 +201,7 @@ std::vector<hipStream_t> concurrent_streams(int wanted, bool probe) {
     (ok ? kept : spare).push_back(s);
   }
   for (hipStream_t s : spare) (void)hipStreamDestroy(s);
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(a_end), (void)hipEventDestroy(b_start);
   if (std::getenv("LGICP_TRACE"))
     fprintf(stderr, "[lgicp] streams: %zu kept of %zu created\n", kept.size(), kept.size() + spare.size());
   return kept;
