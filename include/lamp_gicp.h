@@ -279,6 +279,21 @@ int lgicp_teaser_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const f
                                    size_t n_tgt, const float guess[16], float T_out[16],
                                    int32_t* used_teaser, int32_t* n_matches, int32_t* n_clique);
 
+/* No counterpart in the reference.  lgicp_nn_search for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc):
+ * the same search with the same bits out, but every buffer is the caller's DEVICE memory
+ * (d_src_xyz / d_tgt_xyz packed xyz floats, d_idx[n_src], d_d2[n_src]) and all working memory is
+ * one static device array of the library (about 2.6 MiB per GPU, held until the process ends), so
+ * the call performs no hipMalloc / hipFree.  Each cloud may hold at most LGICP_STATIC_MAX_POINTS
+ * points; larger inputs are rejected with LGICP_E_INVALID.  T is read on the host at call time.
+ * hip_stream = NULL: runs on the context's stream and returns when the results are in d_idx / d_d2;
+ * otherwise a hipStream_t on the context's device: the work is enqueued there and the call returns
+ * at once.  All calls on one GPU share the static array: calls that overlap on one GPU race. */
+#define LGICP_STATIC_MAX_POINTS 65536
+int lgicp_nn_search_static(lgicp_ctx* ctx, const float T[16], const float* d_src_xyz, size_t n_src,
+                           const float* d_tgt_xyz, size_t n_tgt, int32_t* d_idx, float* d_d2,
+                           void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

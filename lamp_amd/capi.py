@@ -19,7 +19,7 @@ EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_
            "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh",
            "lgicp_harris_keypoints", "lgicp_sac_initial_alignment",
            "lgicp_teaser_initial_alignment", "lgicp_compute_normals", "lgicp_icp_observability",
-           "lgicp_voxel_grid", "lgicp_random_sample"]
+           "lgicp_voxel_grid", "lgicp_random_sample", "lgicp_nn_search_static"]
 
 
 class Config(C.Structure):
@@ -124,6 +124,9 @@ def lib():
                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
         L.lgicp_random_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                           C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+        L.lgicp_nn_search_static.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
         _lib = L
     return _lib
 
@@ -238,6 +241,13 @@ class Context:
         self._check(lib().lgicp_nn_search(self._h, _ptr(T), _ptr(src), len(src), _ptr(tgt),
                                           len(tgt), _ptr(idx), _ptr(d2), n_splits))
         return idx, d2
+
+    def nn_search_static(self, T, d_src, n_src, d_tgt, n_tgt, d_idx, d_d2, stream=None):
+        """lgicp_nn_search_static: the d_* arguments are device addresses (ints)."""
+        T = _f32(T).reshape(16)
+        return self._check(lib().lgicp_nn_search_static(
+            self._h, _ptr(T), C.c_void_p(d_src), n_src, C.c_void_p(d_tgt), n_tgt,
+            C.c_void_p(d_idx), C.c_void_p(d_d2), C.c_void_p(stream) if stream else None))
 
     def covariances_from_normals(self, normals):
         nrm = _f32(normals).reshape(-1, 3)

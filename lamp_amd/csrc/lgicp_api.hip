@@ -266,6 +266,10 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
                 cfg->device, prop.gcnArchName);
   if (hipSetDevice(cfg->device) != hipSuccess)
     return fail(nullptr, LGICP_E_HIP, "hipSetDevice failed");
+  {
+    const int rc = static_scratch_init(cfg->device);
+    if (rc != LGICP_OK) return rc;
+  }
   lgicp_ctx* ctx = new lgicp_ctx();
   ctx->cfg = *cfg;
   std::memset(&ctx->stats, 0, sizeof(ctx->stats));

@@ -264,6 +264,10 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
 int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], float T_out[16],
                   int* used, int* n_clique);
 
+// device address of the static scratch array behind lgicp_nn_search_static, looked up once per
+// device; `device` must be the current device
+int static_scratch_init(int device);
+
 inline int fail(lgicp_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
