@@ -466,25 +466,65 @@ static int feature_knn_table(lgicp_ctx* ctx, const CloudFeatures& src, const Clo
 }
 
 // teaser::clique_rotation_host with the sums over the pairwise differences on the device.
-// Runs on a stream of its own: several pairs are solved at once from different host threads.
-// Returns false when the device refuses (the caller reports it).
-static bool clique_rotation_device(const std::vector<double>& cs, const std::vector<double>& cd,
+// Runs on a stream of the calling thread: several pairs are solved at once from different host
+// threads.  Returns false when the device refuses (the caller reports it).
+namespace {
+// Stream and buffers of the clique rotation search, one set per host thread (several pairs are
+// solved at once from different threads) and reused from clique to clique; released when the
+// thread ends.  Bound to the device that was current when they were made.
+struct CliqueDev {
+  int device = -1;
+  hipStream_t st = nullptr;
+  DevBuf<double> cs, cd, w, partial, out;
+  void release() {
+    if (device >= 0) {
+      int cur = -1;
+      (void)hipGetDevice(&cur);
+      if (cur != device) (void)hipSetDevice(device);
+      cs.release(), cd.release(), w.release(), partial.release(), out.release();
+      if (st) (void)hipStreamDestroy(st);
+      if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    }
+    st = nullptr;
+    device = -1;
+  }
+  bool bind(int dev) {
+    if (device == dev && st) return true;
+    release();
+    if (hipSetDevice(dev) != hipSuccess) return false;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+      st = nullptr;
+      return false;
+    }
+    device = dev;
+    return true;
+  }
+  ~CliqueDev() { release(); }
+};
+}  // namespace
+
+static bool clique_rotation_device(int device, const std::vector<double>& cs, const std::vector<double>& cd,
                                    const lgicp::teaser::Params& p, double R[9]) {
   namespace tz = lgicp::teaser;
   const int m = (int)(cs.size() / 3);
   for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-  hipStream_t st = nullptr;
-  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+  thread_local CliqueDev dev;
+  if (!dev.bind(device)) return false;
+  hipStream_t st = dev.st;
   bool ok = false;
   {
-    Scratch dev;
     const dim3 grid((m + lgicp::GNC_THREADS - 1) / lgicp::GNC_THREADS, m);
     const int n_partial = (int)(grid.x * grid.y);
-    double* d_cs = dev.alloc<double>(cs.size());
-    double* d_cd = dev.alloc<double>(cd.size());
-    double* d_w = dev.alloc<double>((size_t)m * m);
-    double* d_partial = dev.alloc<double>((size_t)n_partial * lgicp::GNC_VALUES);
-    double* d_out = dev.alloc<double>(lgicp::GNC_VALUES);
+    if (dev.cs.reserve(cs.size()) != hipSuccess || dev.cd.reserve(cd.size()) != hipSuccess ||
+        dev.w.reserve((size_t)m * m) != hipSuccess ||
+        dev.partial.reserve((size_t)n_partial * lgicp::GNC_VALUES) != hipSuccess ||
+        dev.out.reserve(lgicp::GNC_VALUES) != hipSuccess)
+      return false;
+    double* d_cs = dev.cs.p;
+    double* d_cd = dev.cd.p;
+    double* d_w = dev.w.p;
+    double* d_partial = dev.partial.p;
+    double* d_out = dev.out.p;
     double out[lgicp::GNC_VALUES];
     auto step = [&](lgicp::GncStep k) -> bool {
       hipLaunchKernelGGL(lgicp::gnc_step_kernel, grid, dim3(lgicp::GNC_THREADS), 0, st, d_cs, d_cd, m,
@@ -495,8 +535,7 @@ static bool clique_rotation_device(const std::vector<double>& cs, const std::vec
              hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
     };
-    if (d_cs && d_cd && d_w && d_partial && d_out &&
-        hipMemcpyAsync(d_cs, cs.data(), sizeof(double) * cs.size(), hipMemcpyHostToDevice, st) == hipSuccess &&
+    if (hipMemcpyAsync(d_cs, cs.data(), sizeof(double) * cs.size(), hipMemcpyHostToDevice, st) == hipSuccess &&
         hipMemcpyAsync(d_cd, cd.data(), sizeof(double) * cd.size(), hipMemcpyHostToDevice, st) == hipSuccess) {
       ok = true;
       double nb2 = p.noise_bound * p.noise_bound;
@@ -534,7 +573,9 @@ static bool clique_rotation_device(const std::vector<double>& cs, const std::vec
       }
     }
   }
-  (void)hipStreamDestroy(st);
+  // a failed call may have left work queued on the stream: nothing may still read the buffers
+  // when the next clique overwrites them
+  if (!ok) (void)hipStreamSynchronize(st);
   return ok;
 }
 
@@ -558,10 +599,15 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
   if (n <= 10) return LGICP_OK;  // IcpLoopComputation.cc:1002
   // the consistency graph is a dense n x n bit matrix: 65536 matches are 512 MiB of rows
   constexpr int kMaxMatches = 65536;
-  if (n > kMaxMatches)
-    return fail(ctx, LGICP_E_UNSUPPORTED,
-                "TEASER++ initialisation: %d descriptor matches exceed the %d the consistency "
-                "graph is sized for (raise harris_threshold or harris_radius)", n, kMaxMatches);
+  if (n > kMaxMatches) {
+    // a per-pair outcome, not a call-level error: the pair keeps its odometry guess (what the
+    // reference does whenever TEASER++ does not produce a better transform,
+    // IcpLoopComputation.cc:1065-1074) and the other pairs of the submit go on
+    if (std::getenv("LGICP_TRACE"))
+      std::fprintf(stderr, "[lgicp] teaser: %d descriptor matches exceed the %d the consistency graph "
+                   "is sized for; the pair keeps its guess\n", n, kMaxMatches);
+    return LGICP_OK;
+  }
   std::vector<double>& s = job->src;
   std::vector<double>& d = job->dst;
   s.resize((size_t)3 * n);
@@ -618,7 +664,7 @@ int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], f
         if (cs.size() / 3 < 128)
           tz::clique_rotation_host(cs, cd, p, R);
         else
-          device_ok = clique_rotation_device(cs, cd, p, R);
+          device_ok = clique_rotation_device(ctx->cfg.device, cs, cd, p, R);
       });
   if (!device_ok)
     return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: rotation search over a clique of %d matches "

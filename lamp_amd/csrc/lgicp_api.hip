@@ -618,6 +618,9 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     bool closed = false;
     std::atomic<int> rc_finish{LGICP_OK};
     auto worker = [&]() {
+      // HIP's current device is per thread and starts at 0: the rotation search of large cliques
+      // allocates and launches from this thread
+      if (hipSetDevice(cfg.device) != hipSuccess) rc_finish.store(LGICP_E_HIP);
       for (;;) {
         int j;
         {
@@ -815,8 +818,8 @@ hipError_t spin_until(hipEvent_t ev) {
   }
 }
 
-int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate* cand,
-              lgicp_result* out) {
+int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate* cand,
+                   lgicp_result* out, bool explicit_guess) {
   const bool trace_t = std::getenv("LGICP_TRACE") != nullptr;
   const auto t_enter = std::chrono::steady_clock::now();
   auto since = [&](const char* what) {
@@ -1027,7 +1030,8 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
 
   // ---- FEATURES / TEASERPP initialisation -----------------------------------------------------
   std::vector<char> init_rejected((size_t)n_pairs, 0);
-  if (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP) {
+  if (!explicit_guess &&
+      (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP)) {
     const int rc = initialise_from_features(ctx, bp, h_clouds, cand, out, h_pairs, h_state, init_rejected);
     if (rc != LGICP_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDev) * n_pairs,
@@ -1276,6 +1280,17 @@ int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate
   return LGICP_OK;
 }
 
+// explicit_guess: the pairs' guesses are the caller's and go to GICP as they are, whatever the
+// context's initialisation method says (lgicp_align).  On an error the slot's stream is drained
+// before returning: kernels already queued still write the pinned flags and the arena, which the
+// next batch of the slot clears and reuses.
+int run_batch(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate* cand,
+              lgicp_result* out, bool explicit_guess = false) {
+  const int rc = run_batch_impl(ctx, W, bp, cand, out, explicit_guess);
+  if (rc != LGICP_OK) (void)hipStreamSynchronize(W->stream);
+  return rc;
+}
+
 }  // namespace
 
 namespace {
@@ -1452,7 +1467,8 @@ extern "C" int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* sr
     std::memset(&r, 0, sizeof(r));
     reset_submit_stats(ctx->stats);
     std::memset(&ctx->slot[0].stats, 0, sizeof(lgicp_stats));
-    rc = hipSetDevice(ctx->cfg.device) == hipSuccess ? run_batch(ctx, &ctx->slot[0], bp, &c, &r)
+    rc = hipSetDevice(ctx->cfg.device) == hipSuccess ? run_batch(ctx, &ctx->slot[0], bp, &c, &r,
+                                                                 /*explicit_guess=*/true)
                                                      : LGICP_E_HIP;
     merge_stats(ctx->stats, ctx->slot[0].stats);
     ctx->stats.total_ms = ctx->slot[0].stats.total_ms;

@@ -206,8 +206,20 @@ void GpuIcpLoopComputation::ComputeTransforms() {
   std::vector<lgicp_result> results(batch.size());
   for (size_t i = 0; i < batch.size(); ++i) fill_candidate(batch[i], &cands[i]);
   if (lgicp_submit(ctx_, cands.data(), cands.size(), results.data()) != LGICP_OK) {
-    std::fprintf(stderr, "GpuIcpLoopComputation: %s\n", lgicp_last_error(ctx_));
-    return;
+    // The reference fails per pair and never loses the rest of its queue (every `return false` of
+    // PerformAlignment drops one candidate): a call-level error of the batch is retried one
+    // candidate at a time, so that only the candidates the engine cannot process are dropped.
+    std::fprintf(stderr, "GpuIcpLoopComputation: batch of %zu failed (%s); retrying per candidate\n",
+                 batch.size(), lgicp_last_error(ctx_));
+    for (size_t i = 0; i < batch.size(); ++i) {
+      if (lgicp_submit(ctx_, &cands[i], 1, &results[i]) == LGICP_OK) continue;
+      std::fprintf(stderr, "GpuIcpLoopComputation: candidate %llu -> %llu dropped: %s\n",
+                   (unsigned long long)cands[i].key_from, (unsigned long long)cands[i].key_to,
+                   lgicp_last_error(ctx_));
+      results[i].key_from = cands[i].key_from;
+      results[i].key_to = cands[i].key_to;
+      results[i].status = LGICP_PAIR_NOT_CONVERGED;
+    }
   }
   for (size_t i = 0; i < batch.size(); ++i) {
     const lgicp_result& r = results[i];

@@ -97,31 +97,53 @@ def gather_records(records, dist, rank, world, device=None, equal_counts=False):
 class RecordGatherer:
     """The same gather for a loop that sends the same number of records every time: staging
     buffers (pinned host, device, rank 0's landing area) are allocated once, the per-rank
-    parts arrive in one contiguous device tensor and reach the host in a single copy."""
+    parts arrive in one contiguous device tensor and reach the host in a single copy.
 
-    def __init__(self, dist, rank, world, n_records, device):
+    counts: records held by each rank (ranks may hold different numbers: every rank sends
+    max(counts) rows, rank 0 keeps the first counts[r] of rank r's).  An int means every rank
+    holds that many."""
+
+    def __init__(self, dist, rank, world, counts, device):
         import torch
-        self.dist, self.rank, self.world, self.n = dist, rank, world, n_records
+        if isinstance(counts, int):
+            counts = [counts] * world
+        if len(counts) != world:
+            raise ValueError("one count per rank")
+        self.dist, self.rank, self.world = dist, rank, world
+        self.counts = [int(c) for c in counts]
+        self.n = max(self.counts + [1])
         pin = device.type == "cuda"
-        self.h_in = torch.zeros((n_records, RESULT_WIDTH), dtype=torch.float64, pin_memory=pin)
-        self.d_in = torch.zeros((n_records, RESULT_WIDTH), dtype=torch.float64, device=device)
+        self.h_in = torch.zeros((self.n, RESULT_WIDTH), dtype=torch.float64, pin_memory=pin)
+        self.d_in = torch.zeros((self.n, RESULT_WIDTH), dtype=torch.float64, device=device)
         self.d_all = self.h_all = None
+        self._sent = None  # event after the last gather on this rank (device runs only)
         if rank == 0:
-            self.d_all = torch.zeros((world, n_records, RESULT_WIDTH), dtype=torch.float64, device=device)
-            self.h_all = torch.zeros((world, n_records, RESULT_WIDTH), dtype=torch.float64, pin_memory=pin)
+            self.d_all = torch.zeros((world, self.n, RESULT_WIDTH), dtype=torch.float64, device=device)
+            self.h_all = torch.zeros((world, self.n, RESULT_WIDTH), dtype=torch.float64, pin_memory=pin)
 
     def gather(self, records):
-        """records: [n_records, RESULT_WIDTH] float64.  Returns [world * n_records, RESULT_WIDTH]
-        on rank 0 (a view of the landing buffer, valid until the next call), None elsewhere."""
+        """records: [counts[rank], RESULT_WIDTH] float64.  Returns [sum(counts), RESULT_WIDTH] on
+        rank 0 (rank order, then each rank's own order), None elsewhere."""
         import torch
-        if records.shape != (self.n, RESULT_WIDTH):
-            raise ValueError(f"expected {(self.n, RESULT_WIDTH)} records, got {records.shape}")
-        np.copyto(self.h_in.numpy(), records)
+        mine = self.counts[self.rank]
+        if records.shape != (mine, RESULT_WIDTH):
+            raise ValueError(f"expected {(mine, RESULT_WIDTH)} records, got {records.shape}")
+        # the previous call's asynchronous upload and collective may still be reading the
+        # staging buffers: wait for them on every rank before rewriting
+        if self._sent is not None:
+            self._sent.synchronize()
+        np.copyto(self.h_in.numpy()[:mine], records)
         self.d_in.copy_(self.h_in, non_blocking=True)
         self.dist.gather(self.d_in, list(self.d_all.unbind(0)) if self.rank == 0 else None, dst=0)
+        if self.d_in.is_cuda:
+            self._sent = torch.cuda.Event()
+            self._sent.record()
         if self.rank != 0:
             return None
         self.h_all.copy_(self.d_all, non_blocking=True)
         if self.d_all.is_cuda:
             torch.cuda.current_stream().synchronize()
-        return self.h_all.numpy().reshape(self.world * self.n, RESULT_WIDTH)
+        h = self.h_all.numpy()
+        if all(c == self.n for c in self.counts):
+            return h.reshape(self.world * self.n, RESULT_WIDTH)
+        return np.concatenate([h[r, :self.counts[r]] for r in range(self.world)], axis=0)

@@ -81,6 +81,11 @@ typedef struct lo_gicp_params {
   int solver;                /* LO_SOLVER_BFGS (reference) | LO_SOLVER_GN (what the GPU runs) */
   int use_kdtree;            /* 1: kd-tree lookups (reference-like cost), 0: brute force    */
   int threads;               /* omp threads of the lookup loop (gicp.hpp:463-465)           */
+  /* measurement knobs, not in the reference */
+  double gradient_tol;       /* BFGS gradient tolerance; the reference hard-codes 1e-2 (gicp.hpp:250) */
+  int gn_cycle_exit;         /* 1 (default): the Gauss-Newton back end's limit-cycle exit; 0: off */
+  int residual_double;       /* 0 (default, the reference): BFGS functor rounds T*p to float
+                                (gicp.hpp:307-310); 1: residual in double from the float matrix */
 } lo_gicp_params;
 
 void lo_gicp_default_params(lo_gicp_params* p);
@@ -92,6 +97,8 @@ typedef struct lo_gicp_result {
   int last_num_correspondences;   /* m of the last outer iteration                        */
   int failure;                    /* 1: a covariance set was empty (cloud smaller than k) */
   double last_delta;
+  int cycle_exit;                 /* 1: left the loop through the Gauss-Newton cycle exit */
+  int pad_;
 } lo_gicp_result;
 
 /* MultithreadedGICP::computeTransformation (gicp.hpp:405-617) driven as Registration::align.

@@ -30,13 +30,15 @@ class GicpParams(C.Structure):
                 ("rotation_epsilon", C.c_double), ("max_iterations", C.c_int),
                 ("max_inner_iterations", C.c_int), ("k_correspondences", C.c_int),
                 ("gicp_epsilon", C.c_double), ("cov_from_knn", C.c_int), ("solver", C.c_int),
-                ("use_kdtree", C.c_int), ("threads", C.c_int)]
+                ("use_kdtree", C.c_int), ("threads", C.c_int), ("gradient_tol", C.c_double),
+                ("gn_cycle_exit", C.c_int), ("residual_double", C.c_int)]
 
 
 class GicpResult(C.Structure):
     _fields_ = [("final_transformation", C.c_float * 16), ("converged", C.c_int),
                 ("iterations", C.c_int), ("last_num_correspondences", C.c_int),
-                ("failure", C.c_int), ("last_delta", C.c_double)]
+                ("failure", C.c_int), ("last_delta", C.c_double), ("cycle_exit", C.c_int),
+                ("pad_", C.c_int)]
 
 
 class Pose(C.Structure):

@@ -153,6 +153,28 @@ def test_align_matches_oracle(ctx, n, seed, rd, tr):
     assert abs(fit - r["fitness"]) <= 1e-5 * abs(fit)
 
 
+def test_align_uses_the_callers_guess_whatever_the_init_method():
+    """lgicp_align on a context with the reference's default initialisation (FEATURES, what
+    lgicp_default_config sets) and with TEASERPP: the explicit guess goes to GICP as it is, no
+    SAC-IA / TEASER++ replaces or rejects it."""
+    from lamp_amd import capi
+    src, sn, tgt, tn, T = F.make_pair(3000, 5, rot_deg=2.0, trans=0.15)
+    guess = np.eye(4, dtype=np.float32)
+    guess[:3, 3] = [0.02, -0.03, 0.01]
+    ref = O.gicp_align(O.base_gicp_params(solver=O.SOLVER_GN, use_kdtree=1), src, sn, tgt, tn, guess)
+    for method in (capi.INIT_FEATURES, capi.INIT_TEASERPP):
+        c = capi.Context(init_method=method)
+        try:
+            assert c.cfg.init_method == method
+            r = c.align(src, sn, tgt, tn, guess)
+        finally:
+            c.close()
+        assert r["converged"] and ref["converged"]
+        ang, te = _rot_err(ref["T"], r["T"])
+        assert ang < 1e-5 and te < 1e-5, (method, ang, te)
+        assert r["iterations"] == ref["iterations"]
+
+
 # ------------------------------------------------------------------ batch path
 def _register(ctx, key, xyz, nrm, t=(0, 0, 0), q=(1, 0, 0, 0)):
     assert ctx.add_keyframe(key, xyz, nrm) == 1
