@@ -107,7 +107,8 @@ typedef struct lgicp_config {
                                  exhaustive 1-NN kernel (2, 4, 8); [1] its target splits;
                                  [2] 1 = use the exhaustive 1-NN kernel instead of the pruned
                                  one; [3] first-round radius of the pruned search in mm;
-                                 [5] 1 = host round trip after every outer iteration; [6] 1 = no
+                                 [5] bit 0 = host round trip after every outer iteration, bit 1 = no
+                                 limit-cycle exit from the outer loop; [6] 1 = no
                                  seeding of a lookup with the previous match, 2 = seeding but no
                                  lookup certificates (every query searches in every pass; the
                                  results are the same bits either way); [7] parts of a
@@ -160,6 +161,9 @@ typedef struct lgicp_stats {
                                    pairs and outer iterations, last submit */
   double reduce_inliers;        /* correspondences inside corr_dist among them */
   uint64_t reduce_launches;     /* launches of the linearise/reduce kernel, last submit */
+  uint64_t cycle_exits;         /* pairs of the last submit that left the outer loop because their
+                                   transformation revisited one of its last 16 values (an exit the
+                                   reference does not have; reserved[5] bit 1 switches it off) */
 } lgicp_stats;
 
 typedef struct lgicp_ctx lgicp_ctx;

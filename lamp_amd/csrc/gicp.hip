@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
   for (int i = 0; i < 16; ++i) T[i] = S.T[i];
   for (int i = 0; i < 16; ++i) Tprev[i] = T[i];  // previous_transformation_ = transformation_
   bool done = false;
-  bool failed = false, converged = false;
+  bool failed = false, converged = false, cycle = false;
   double delta = 0.;
   int it_out = S.iterations;
   unsigned long long h_prev = 0;
@@ -581,7 +581,6 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     // observed).  A transformation already used for the lookups within the last 16 iterations
     // proves that no further progress is possible: stop as converged (the reference's BFGS
     // reports NoProgress in the same spot).
-    bool cycle = false;
     {
       // both hashes in one pass: even lanes hash T, odd lanes Tprev
       float W[16];
@@ -594,9 +593,11 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
       h_prev = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(hv >> 32), 1) << 32) |
                (unsigned)__builtin_amdgcn_readlane((int)(unsigned)hv, 1);
       const int n_hist = it_out - 1 < 16 ? it_out - 1 : 16;
-      cycle = __ballot(lane < n_hist && my_hist == h) != 0;
+      cycle = sp.cycle_exit && __ballot(lane < n_hist && my_hist == h) != 0;
     }
-    if (it_out >= sp.max_iterations || delta < 1 || cycle) {
+    const bool by_rule = it_out >= sp.max_iterations || delta < 1;
+    cycle = cycle && !by_rule;
+    if (by_rule || cycle) {
       converged = true;
       for (int i = 0; i < 16; ++i) Tprev[i] = T[i];
       done = true;
@@ -615,6 +616,7 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     for (int i = 0; i < 16; ++i) S.T[i] = T[i];
     S.Thash[(it_out - 1) % 16] = h_prev;
     if (converged) S.converged = 1;
+    if (cycle) S.cycle = 1;
   }
   for (int i = 0; i < 16; ++i) S.Tprev[i] = Tprev[i];
   if (done) {

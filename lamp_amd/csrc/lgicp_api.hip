@@ -743,6 +743,7 @@ void finish_pairs(const lgicp_config& cfg, const BatchPlan& bp, const std::vecto
     S.outer_iterations += (uint64_t)s.iterations;
     S.reduce_points += (double)h_pairs[p].n_src * (double)s.iterations;
     S.reduce_inliers += s.m_sum;
+    S.cycle_exits += (uint64_t)(s.cycle != 0);
     S.nn_distance_evals +=
         (double)h_pairs[p].n_src * (double)h_pairs[p].n_tgt * (double)(s.iterations + 1);
     double post[NPOST] = {0};
@@ -1054,6 +1055,8 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   sp.tf_epsilon = cfg.tf_epsilon;
   sp.max_iterations = cfg.iterations;
   sp.max_inner_iterations = cfg.optimizer_iterations;
+  sp.cycle_exit = (cfg.reserved[5] & 2) ? 0 : 1;
+  sp.pad = 0;
   // "Left the loop" flags, one per pair, raised by the solve kernel straight in pinned host memory
   // (entry 0 is unused): no copy and no second stream between the device and the host's view
   int* const h_live = W->h_done;
@@ -1146,7 +1149,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     return LGICP_OK;
   };
   const int n_active0 = (int)active.size();
-  const bool lagged = !ctx->nn_exhaustive && cfg.reserved[5] != 1;
+  const bool lagged = !ctx->nn_exhaustive && !(cfg.reserved[5] & 1);
   if (!active.empty()) {
     int rc = enqueue_iteration(0);
     if (rc != LGICP_OK) return rc;
@@ -1305,6 +1308,7 @@ void merge_stats(lgicp_stats& into, const lgicp_stats& d) {
   into.nn_executed_evals += d.nn_executed_evals;
   into.reduce_points += d.reduce_points, into.reduce_inliers += d.reduce_inliers;
   into.reduce_launches += d.reduce_launches;
+  into.cycle_exits += d.cycle_exits;
   if (d.last_nn_evals_per_launch > 0) {
     into.last_nn_kernel_ms = d.last_nn_kernel_ms;
     into.last_nn_evals_per_launch = d.last_nn_evals_per_launch;
@@ -1315,6 +1319,7 @@ void reset_submit_stats(lgicp_stats& s) {
   s.nn_ms = s.reduce_ms = s.solve_ms = s.cov_ms = s.post_ms = s.total_ms = 0;
   s.nn_executed_evals = s.reduce_points = s.reduce_inliers = 0;
   s.reduce_launches = 0;
+  s.cycle_exits = 0;
 }
 
 }  // namespace

@@ -82,7 +82,7 @@ struct PairState {
   int active;  // still inside the outer loop
   int failed;  // optimiser "exception" (fewer than 4 correspondences)
   int m;       // correspondences of the last outer iteration
-  int pad;
+  int cycle;   // 1: left the loop through the limit-cycle exit
   double m_sum;  // correspondences summed over the outer iterations (statistics only)
 };
 
@@ -92,6 +92,8 @@ struct SolveParams {
   double tf_epsilon;
   int max_iterations;
   int max_inner_iterations;
+  int cycle_exit;  // 1: stop a pair whose transformation revisits one of its last 16 values
+  int pad;
 };
 
 // ---- launchers (each enqueues on `stream`, returns the hipError_t of the launch) ----------

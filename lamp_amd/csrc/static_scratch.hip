@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void static_nn_setup_kernel(
       s->Thash[i] = 0ull;
     }
     s->delta = 0.0, s->iterations = 0, s->converged = 0, s->active = 1, s->failed = 0;
-    s->m = 0, s->pad = 0, s->m_sum = 0.0;
+    s->m = 0, s->cycle = 0, s->m_sum = 0.0;
   }
 }
 

@@ -109,6 +109,13 @@ int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* sr
                   const float guess[16], lo_gicp_result* out, int32_t* trace_idx, float* trace_T,
                   int trace_cap);
 
+/* measurement helper (not a reference function): objective and gradient of gicp.hpp:290-402 at the
+ * stationary point T claims to be — lookups and Mahalanobis matrices of one outer iteration started
+ * from T, functor evaluated at x = 0, residual in double.  Returns -1 with fewer than 4 matches. */
+int lo_gicp_objective_at(const lo_gicp_params* p, const float* src_xyz, const float* src_normals,
+                         int n_src, const float* tgt_xyz, const float* tgt_normals, int n_tgt,
+                         const float T[16], double* f, double g[6], int* m_out);
+
 /* one evaluation of the BFGS functor (gicp.hpp:290-402) for unit tests:
  * f and g[6] at x for given correspondences; mahal9 is [n_src][9] indexed by source index. */
 void lo_gicp_cost_grad(const float* src_xyz_guess, const float* tgt_xyz, const int32_t* src_idx,

@@ -165,6 +165,7 @@ typedef struct {
   int m;
   const double* mahal; /* [n_src][9] */
   long n_evals;
+  int residual_double; /* measurement knob: 1 = T*p in double instead of the reference's float */
 } lo_functor;
 
 /* applyState (gicp.hpp:619-634) on t = identity:
@@ -269,8 +270,12 @@ static void functor_fdf(lo_functor* F, const double x[6], double* f_out, double*
     const float* pt = F->tgt + 3 * F->ti[i];
     float pp[3];
     xform4(T, ps, pp);
-    const double res[3] = {(double)(pp[0] - pt[0]), (double)(pp[1] - pt[1]),
-                           (double)(pp[2] - pt[2])};
+    double res[3] = {(double)(pp[0] - pt[0]), (double)(pp[1] - pt[1]), (double)(pp[2] - pt[2])};
+    if (F->residual_double)
+      for (int a = 0; a < 3; ++a)
+        res[a] = ((double)T[a * 4] * (double)ps[0] + (double)T[a * 4 + 1] * (double)ps[1] +
+                  (double)T[a * 4 + 2] * (double)ps[2] + (double)T[a * 4 + 3]) -
+                 (double)pt[a];
     const double* M = F->mahal + 9 * (size_t)F->si[i];
     const double temp[3] = {M[0] * res[0] + M[1] * res[1] + M[2] * res[2],
                             M[3] * res[0] + M[4] * res[1] + M[5] * res[2],
@@ -298,7 +303,7 @@ static void functor_fdf(lo_functor* F, const double x[6], double* f_out, double*
 void lo_gicp_cost_grad(const float* src_xyz_guess, const float* tgt_xyz, const int32_t* src_idx,
                        const int32_t* tgt_idx, int m, const double* mahal9, const double x[6],
                        double* f, double g[6]) {
-  lo_functor F = {src_xyz_guess, tgt_xyz, src_idx, tgt_idx, m, mahal9, 0};
+  lo_functor F = {src_xyz_guess, tgt_xyz, src_idx, tgt_idx, m, mahal9, 0, 0};
   functor_fdf(&F, x, f, g);
 }
 
@@ -643,7 +648,7 @@ static int bfgs_step(lo_bfgs* s, double x[6]) {
 }
 
 /* estimateRigidTransformationBFGS (gicp.hpp:217-287). returns 0 ok, -1 exception */
-static int estimate_bfgs(lo_functor* F, int max_inner, float T[16]) {
+static int estimate_bfgs(lo_functor* F, int max_inner, double gradient_tol, float T[16]) {
   if (F->m < 4) return -1; /* NotEnoughPointsException */
   double x[6];
   x[0] = T[3];
@@ -655,7 +660,7 @@ static int estimate_bfgs(lo_functor* F, int max_inner, float T[16]) {
   lo_bfgs s;
   bfgs_init(&s, F, x);
   int inner = 0, result;
-  const double gradient_tol = 1e-2;
+  /* gradient_tol: 1e-2 in the reference (gicp.hpp:250) */
   do {
     inner++;
     result = bfgs_step(&s, x);
@@ -899,6 +904,9 @@ void lo_gicp_default_params(lo_gicp_params* p) {
   p->solver = LO_SOLVER_BFGS;
   p->use_kdtree = 1;
   p->threads = 1;
+  p->gradient_tol = 1e-2;          /* gicp.hpp:250 */
+  p->gn_cycle_exit = 1;
+  p->residual_double = 0;
 }
 
 int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* src_normals,
@@ -992,9 +1000,11 @@ int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* sr
       memcpy(trace_T + 16 * (size_t)nr_iterations, T, sizeof(float) * 16);
     out->last_num_correspondences = m;
     memcpy(Tprev, T, sizeof(T)); /* previous_transformation_ = transformation_ */
-    lo_functor F = {output, tgt_xyz, si, ti, m, mahal, 0};
-    const int rc = (p->solver == LO_SOLVER_GN) ? estimate_gn(&F, p->max_inner_iterations, T)
-                                               : estimate_bfgs(&F, p->max_inner_iterations, T);
+    lo_functor F = {output, tgt_xyz, si, ti, m, mahal, 0, p->residual_double};
+    const int rc = (p->solver == LO_SOLVER_GN)
+                       ? estimate_gn(&F, p->max_inner_iterations, T)
+                       : estimate_bfgs(&F, p->max_inner_iterations,
+                                       p->gradient_tol > 0 ? p->gradient_tol : 1e-2, T);
     if (rc != 0) break; /* catch (PCLException) -> break, converged_ stays false */
     delta = 0.;
     for (int k = 0; k < 4; ++k)
@@ -1011,7 +1021,7 @@ int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* sr
      * already used for the lookups within the last LO_CYCLE_HISTORY iterations proves that no
      * further progress is possible: stop as converged. */
     int cycle = 0;
-    if (p->solver == LO_SOLVER_GN) {
+    if (p->solver == LO_SOLVER_GN && p->gn_cycle_exit) {
       const uint64_t h = hash_T(T);
       const int n_hist = nr_iterations - 1 < LO_CYCLE_HISTORY ? nr_iterations - 1 : LO_CYCLE_HISTORY;
       for (int k = 0; k < n_hist; ++k)
@@ -1021,6 +1031,7 @@ int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* sr
     }
     if (nr_iterations >= p->max_iterations || delta < 1 || cycle) {
       converged = 1;
+      out->cycle_exit = cycle && !(nr_iterations >= p->max_iterations || delta < 1);
       memcpy(Tprev, T, sizeof(T));
     }
   }
@@ -1040,6 +1051,76 @@ int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* sr
   free(si);
   free(ti);
   return 0;
+}
+
+/* Measurement helper, not a reference function: the reference's objective (gicp.hpp:290-402) and
+ * its gradient at the stationary point an alignment claims.  T plays the part of the guess, the
+ * lookups and Mahalanobis matrices are built as in one outer iteration starting from
+ * transformation_ = identity (gicp.hpp:445-498), and the functor is evaluated at x = 0.  A
+ * transformation at the fixed point of the outer loop has a vanishing gradient here. */
+int lo_gicp_objective_at(const lo_gicp_params* p, const float* src_xyz, const float* src_normals,
+                         int n_src, const float* tgt_xyz, const float* tgt_normals, int n_tgt,
+                         const float T[16], double* f, double g[6], int* m_out) {
+  const int N = n_src;
+  if (N <= 0 || n_tgt <= 0) return -1;
+  double* mahal = (double*)malloc(sizeof(double) * 9 * (size_t)N);
+  double* covT = (double*)malloc(sizeof(double) * 9 * (size_t)n_tgt);
+  double* covS = (double*)malloc(sizeof(double) * 9 * (size_t)N);
+  float* output = (float*)malloc(sizeof(float) * 3 * (size_t)N);
+  int32_t* nn_idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+  float* nn_d = (float*)malloc(sizeof(float) * (size_t)N);
+  int32_t* si = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+  int32_t* ti = (int32_t*)malloc(sizeof(int32_t) * (size_t)N);
+  lo_cov_from_normals(tgt_normals, n_tgt, covT);
+  lo_cov_from_normals(src_normals, N, covS);
+  lo_transform_points_f32(T, src_xyz, N, output);
+  lo_kdtree* tree = lo_kdtree_build(tgt_xyz, n_tgt);
+  lo_kdtree_nn(tree, output, N, nn_idx, nn_d, p->threads);
+  lo_kdtree_free(tree);
+  double R[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = (double)T[i * 4 + j];
+  const double dist_threshold = p->corr_dist * p->corr_dist;
+  int m = 0;
+  for (int i = 0; i < N; ++i) {
+    if (nn_idx[i] < 0 || !((double)nn_d[i] < dist_threshold)) continue;
+    const double* C1 = covS + 9 * (size_t)i;
+    const double* C2 = covT + 9 * (size_t)nn_idx[i];
+    double RC[9], tmp[9];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += R[a * 3 + k] * C1[k * 3 + b];
+        RC[a * 3 + b] = s;
+      }
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += RC[a * 3 + k] * R[b * 3 + k];
+        tmp[a * 3 + b] = s + C2[a * 3 + b];
+      }
+    lo_mat3_inverse(tmp, mahal + 9 * (size_t)i);
+    si[m] = i;
+    ti[m] = nn_idx[i];
+    ++m;
+  }
+  int rc = -1;
+  if (m >= 4) {
+    lo_functor F = {output, tgt_xyz, si, ti, m, mahal, 0, 1};
+    const double x0[6] = {0, 0, 0, 0, 0, 0};
+    functor_fdf(&F, x0, f, g);
+    rc = 0;
+  }
+  if (m_out) *m_out = m;
+  free(mahal);
+  free(covT);
+  free(covS);
+  free(output);
+  free(nn_idx);
+  free(nn_d);
+  free(si);
+  free(ti);
+  return rc;
 }
 
 /* pcl::Registration::getFitnessScore(max_range = DBL_MAX) + the correspondence pass of

@@ -163,6 +163,30 @@ def cov_from_normals(normals):
     return out
 
 
+def gicp_objective_at(params, src_xyz, src_normals, tgt_xyz, tgt_normals, T):
+    """Measurement helper: the reference's objective and gradient (6 Euler parameters) at the
+    stationary point T claims to be.  Returns (f, g[6], m) or None with fewer than 4 matches."""
+    a = [_f32(v) for v in (src_xyz, src_normals, tgt_xyz, tgt_normals)]
+    T = _f32(T).reshape(16)
+    f = C.c_double()
+    g = np.zeros(6, np.float64)
+    m = C.c_int()
+    rc = lib().lo_gicp_objective_at(C.byref(params), _p(a[0], C.c_float), _p(a[1], C.c_float),
+                                    len(a[0]), _p(a[2], C.c_float), _p(a[3], C.c_float), len(a[2]),
+                                    _p(T, C.c_float), C.byref(f), _p(g, C.c_double), C.byref(m))
+    return None if rc != 0 else (f.value, g, m.value)
+
+
+def pose_gap(Ta, Tb):
+    """(rotation angle in rad, translation norm in m) of Ta^-1 Tb.  The angle comes from the
+    antisymmetric part (sin) and the trace (cos) together: arccos of the trace alone cannot
+    resolve angles under ~3e-4 rad when the entries are float32."""
+    dT = np.linalg.inv(np.asarray(Ta, np.float64)) @ np.asarray(Tb, np.float64)
+    R = dT[:3, :3]
+    s = 0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return float(np.arctan2(s, 0.5 * (np.trace(R) - 1.0))), float(np.linalg.norm(dT[:3, 3]))
+
+
 def cov_knn(xyz, k=20, eps=1e-3, threads=1):
     xyz = _f32(xyz)
     out = np.empty((len(xyz), 3, 3), np.float64)
@@ -191,6 +215,7 @@ def gicp_align(params, src_xyz, src_normals, tgt_xyz, tgt_normals, guess=None, t
         "m": res.last_num_correspondences,
         "failure": res.failure,
         "delta": res.last_delta,
+        "cycle_exit": bool(res.cycle_exit),
     }
     if trace_cap > 0:
         out["trace_idx"] = tr_idx

@@ -10,11 +10,16 @@ pytestmark = pytest.mark.gpu
 
 
 def _rot_err(Ta, Tb):
-    # inv(Ta) @ Tb: exactly the identity for equal inputs (a transposed float rotation is not
-    # its exact inverse, which would show up as ~1e-4 rad through the arccos)
-    dT = np.linalg.inv(np.asarray(Ta, np.float64)) @ np.asarray(Tb, np.float64)
-    ang = np.arccos(np.clip((np.trace(dT[:3, :3]) - 1) / 2, -1, 1))
-    return ang, np.linalg.norm(dT[:3, 3])
+    # (angle, translation) of inv(Ta) @ Tb; the angle from sin and cos together (arccos of the
+    # trace alone cannot resolve angles under ~3e-4 rad on float32 matrices)
+    return O.pose_gap(Ta, Tb)
+
+
+def _close_per_entry(got, ref, rtol):
+    """Per-entry relative comparison of a 6x6 matrix; entries below 1e-9 of the largest one (sums
+    that cancel to rounding noise) are compared against that floor instead."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return np.allclose(got, ref, rtol=rtol, atol=1e-9 * np.abs(ref).max())
 
 
 def _oracle_pair(work, a, b, solver):
@@ -28,9 +33,9 @@ def _oracle_pair(work, a, b, solver):
 
 @pytest.mark.parametrize("config,points", [("C1", None), ("C2", None), ("C3", None), ("C5", None)])
 def test_one_pair_of_each_configuration(config, points):
-    """north_star tolerances: pose 1e-4 rad / 1e-4 m, fitness and information 1e-5 relative
-    (against the oracle's Gauss-Newton back end; 1e-3 against its BFGS back end, the measured
-    distance between the two solvers' stopping points)."""
+    """north_star tolerances: pose 1e-4 rad / 1e-4 m, fitness and information 1e-5 relative per
+    entry (against the oracle's Gauss-Newton back end; against its BFGS back end see
+    tests/test_gpu_solver_gap.py, which measures 32 pairs per configuration)."""
     from lamp_amd import capi
     from lamp_amd.workload import Workload
     work = Workload(config, pairs=2, keyframes=2)
@@ -46,14 +51,12 @@ def test_one_pair_of_each_configuration(config, points):
         ang, te = _rot_err(gn["T_icp"], d["T_icp"])
         assert ang < 1e-4 and te < 1e-4, (config, ang, te)
         assert abs(d["fitness"] - gn["fitness"]) <= 1e-5 * gn["fitness"]
-        assert np.allclose(d["covariance"], gn["covariance"], rtol=1e-4,
-                           atol=1e-5 * np.abs(gn["covariance"]).max())
+        assert _close_per_entry(d["covariance"], gn["covariance"], 1e-4)
         src, sn = work.keyframes[a]
         tgt, tn = work.keyframes[b]
         _, idx = O.fitness_score(src, tgt, d["T_icp"])
         _, Ap = O.icp_cov_point_plane(src, tn, idx, d["T_icp"])
-        assert np.allclose(d["information"], Ap / 0.0025, rtol=1e-5,
-                           atol=1e-5 * np.abs(Ap).max() / 0.0025)
+        assert _close_per_entry(d["information"], Ap / 0.0025, 1e-5)
         # the alignment is close to the synthetic truth (sanity, not parity)
         ang, te = _rot_err(work.truth[(a, b)], d["T_icp"])
         assert ang < 5e-3 and te < 2e-2
