@@ -182,6 +182,20 @@ const char* lgicp_last_error(const lgicp_ctx* ctx); /* ctx may be NULL: last cre
  * be NULL (all-zero normals).  Returns 1 if stored, 0 if the key already had a scan. */
 int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const float* normals,
                        size_t n_points, size_t stride_bytes);
+/* The same for `count` keyed scans at once (one device allocation, one upload and one pass of
+ * every registration kernel for the whole batch; a backlog of keyed scans, or a data set, is
+ * registered several times faster this way than scan by scan).  xyz[k] / normals[k] / n_points[k]
+ * describe scan k as above; normals, or single entries of it, may be NULL.  Keys already stored,
+ * or repeated inside the call, are skipped (first wins).  Returns the number of scans stored.
+ * What registration derives on the device is what the reference builds inside every alignment:
+ * the search structure of setInputTarget (lamp_utils/include/lamp_utils/gicp.h:175-209) and the
+ * per-point covariances of computeCovariances (gicp.hpp:422-432), plus NormalizePCloud's
+ * constants (PointCloudUtils.cc:39-59).  The device work is only enqueued: lgicp_submit waits for
+ * it by itself, lgicp_wait_registered does so explicitly. */
+int lgicp_add_keyframes(lgicp_ctx* ctx, size_t count, const uint64_t* keys, const float* const* xyz,
+                        const float* const* normals, const size_t* n_points, size_t stride_bytes);
+/* returns once every keyframe registered so far is resident and indexed on the device */
+int lgicp_wait_registered(lgicp_ctx* ctx);
 /* IcpLoopComputation::KeyedPoseCallback (IcpLoopComputation.cc:394-418): first wins. */
 int lgicp_add_pose(lgicp_ctx* ctx, uint64_t key, const double q_wxyz[4], const double t[3]);
 int lgicp_has_keyframe(const lgicp_ctx* ctx, uint64_t key);

@@ -19,7 +19,7 @@ EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_
            "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh",
            "lgicp_harris_keypoints", "lgicp_sac_initial_alignment",
            "lgicp_teaser_initial_alignment", "lgicp_compute_normals", "lgicp_icp_observability",
-           "lgicp_voxel_grid", "lgicp_random_sample", "lgicp_nn_search_static"]
+           "lgicp_voxel_grid", "lgicp_random_sample", "lgicp_nn_search_static", "lgicp_add_keyframes", "lgicp_wait_registered"]
 
 
 class Config(C.Structure):
@@ -90,6 +90,9 @@ def lib():
         L.lgicp_destroy.argtypes = [C.c_void_p]
         L.lgicp_add_keyframe.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                          C.c_size_t, C.c_size_t]
+        L.lgicp_add_keyframes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t]
+        L.lgicp_wait_registered.argtypes = [C.c_void_p]
         L.lgicp_add_pose.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.lgicp_has_keyframe.argtypes = [C.c_void_p, C.c_uint64]
         L.lgicp_has_pose.argtypes = [C.c_void_p, C.c_uint64]
@@ -180,6 +183,22 @@ class Context:
         nrm = None if normals is None else _f32(normals).reshape(-1, 3)
         return self._check(lib().lgicp_add_keyframe(self._h, key, _ptr(xyz),
                                                     None if nrm is None else _ptr(nrm), len(xyz), 12))
+
+    def add_keyframes(self, keys, clouds, normals=None):
+        """lgicp_add_keyframes: clouds / normals are lists of [n, 3] arrays (normals or single
+        entries of it may be None).  Returns the number of scans stored."""
+        n = len(keys)
+        xs = [_f32(c).reshape(-1, 3) for c in clouds]
+        ns = [None if (normals is None or normals[k] is None) else _f32(normals[k]).reshape(-1, 3)
+              for k in range(n)]
+        karr = (C.c_uint64 * max(n, 1))(*keys)
+        xarr = (C.c_void_p * max(n, 1))(*[x.ctypes.data for x in xs])
+        narr = (C.c_void_p * max(n, 1))(*[None if v is None else v.ctypes.data for v in ns])
+        cnt = (C.c_size_t * max(n, 1))(*[len(x) for x in xs])
+        return self._check(lib().lgicp_add_keyframes(self._h, n, karr, xarr, narr, cnt, 12))
+
+    def wait_registered(self):
+        return self._check(lib().lgicp_wait_registered(self._h))
 
     def add_pose(self, key, q_wxyz, t):
         q = np.ascontiguousarray(q_wxyz, np.float64)

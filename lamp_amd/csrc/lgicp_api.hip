@@ -31,7 +31,6 @@
 #include <thread>
 
 #include "lgicp_internal.h"
-#include "spatial_index.h"
 
 namespace {
 
@@ -75,64 +74,6 @@ void xcd_permute(std::vector<T>& v, std::vector<T>& out) {
 }
 
 }  // namespace
-
-namespace lgicp_detail {
-
-// k-d visiting order on the host, tiles and boxes on the device; the cloud is one segment.
-int build_keyframe_index(lgicp_ctx* ctx, Keyframe* kf, const float* xyz, size_t stride_floats) {
-  const int n = kf->n;
-  kf->n_tiles = (n + SI_TILE - 1) / SI_TILE;
-  kf->n_q = round_up(n, 64);
-  if (n == 0) return LGICP_OK;
-  const std::vector<int> order = si::kd_order(xyz, (size_t)n, stride_floats, SI_TILE);
-  HIP_TRY(ctx, hipMalloc((void**)&kf->d_order, sizeof(int) * (size_t)n));
-  HIP_TRY(ctx, hipMalloc((void**)&kf->d_sxyz, sizeof(float4) * (size_t)kf->n_tiles * SI_TILE));
-  HIP_TRY(ctx, hipMalloc((void**)&kf->d_tmin, sizeof(float4) * (size_t)kf->n_tiles));
-  HIP_TRY(ctx, hipMalloc((void**)&kf->d_tmax, sizeof(float4) * (size_t)kf->n_tiles));
-  HIP_TRY(ctx, hipMalloc((void**)&kf->d_qorder, sizeof(int) * (size_t)kf->n_q));
-  HIP_TRY(ctx, hipMemcpy(kf->d_order, order.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-  IndexSegDev g;
-  std::memset(&g, 0, sizeof(g));
-  g.xyz = kf->d_xyz, g.order = kf->d_order, g.sxyz = kf->d_sxyz, g.tmin = kf->d_tmin;
-  g.tmax = kf->d_tmax, g.qorder = kf->d_qorder;
-  g.point_off = 0, g.tile_off = 0, g.n = n, g.last = 1, g.n_q = kf->n_q;
-  HIP_TRY(ctx, ctx->d_isegs.reserve(1));
-  HIP_TRY(ctx, hipMemcpy(ctx->d_isegs.p, &g, sizeof(g), hipMemcpyHostToDevice));
-  HIP_TRY(ctx, launch_index_fill(ctx->d_isegs.p, 1, n, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return LGICP_OK;
-}
-
-// covariances from the normals and NormalizePCloud constants of a registered keyframe
-int build_keyframe_derived(lgicp_ctx* ctx, Keyframe* kf) {
-  const int n = kf->n;
-  if (n == 0) return LGICP_OK;
-  HIP_TRY(ctx, hipMalloc((void**)&kf->d_cov, sizeof(double) * 6 * (size_t)n));
-  HIP_TRY(ctx, launch_cov_from_normals(kf->d_nrm, n, kf->d_cov, ctx->stream));
-  HIP_TRY(ctx, hipMalloc((void**)&kf->d_rec, sizeof(float4) * 4 * (size_t)n));
-  HIP_TRY(ctx, launch_pack_records(kf->d_xyz, kf->d_cov, n, kf->d_rec, ctx->stream));
-  kf->d_nrm_x = kf->d_nrm;
-  if (kf->normals_missing) {  // ExtractNormals falls back to ComputeNormals (k = 10)
-    HIP_TRY(ctx, hipMalloc((void**)&kf->d_nrm_x, sizeof(float4) * (size_t)n));
-    HIP_TRY(ctx, launch_normals_knn(kf->d_xyz, n, kf->n_pad, std::min(10, n), kf->d_nrm_x, ctx->stream));
-  }
-  CloudDev c;
-  std::memset(&c, 0, sizeof(c));
-  c.xyz = kf->d_xyz, c.n = n, c.n_pad = kf->n_pad;
-  const int id = 0;
-  HIP_TRY(ctx, ctx->d_reg_cloud.reserve(1));
-  HIP_TRY(ctx, ctx->d_reg_ids.reserve(1));
-  HIP_TRY(ctx, hipMemcpy(ctx->d_reg_cloud.p, &c, sizeof(c), hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMemcpy(ctx->d_reg_ids.p, &id, sizeof(id), hipMemcpyHostToDevice));
-  HIP_TRY(ctx, launch_normalize_constants(ctx->d_reg_cloud.p, ctx->d_reg_ids.p, 1, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipMemcpy(&c, ctx->d_reg_cloud.p, sizeof(c), hipMemcpyDeviceToHost));
-  std::memcpy(kf->centroid, c.centroid, sizeof(kf->centroid));
-  kf->factor = c.factor;
-  return LGICP_OK;
-}
-
-}  // namespace lgicp_detail
 
 namespace {
 
@@ -306,9 +247,7 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   (void)hipSetDevice(ctx->cfg.device);
   for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
   for (auto& kv : ctx->scans) kv.second.free_device();
-  ctx->d_isegs.release();
-  ctx->d_reg_cloud.release();
-  ctx->d_reg_ids.release();
+  ctx->reg.destroy();
   delete ctx;
 }
 
@@ -316,41 +255,59 @@ const char* lgicp_last_error(const lgicp_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
+int lgicp_add_keyframes(lgicp_ctx* ctx, size_t count, const uint64_t* keys, const float* const* xyz,
+                        const float* const* normals, const size_t* n_points, size_t stride_bytes) {
+  if (!ctx) return LGICP_E_INVALID;
+  if (count && (!keys || !xyz || !n_points)) return fail(ctx, LGICP_E_INVALID, "null argument");
+  if (stride_bytes < 12 || stride_bytes % 4) return fail(ctx, LGICP_E_INVALID, "bad stride");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  // first insert of a key wins (IcpLoopComputation.cc:380-385), inside the call as well
+  std::vector<KfInput> in;
+  std::unordered_map<uint64_t, int> seen;
+  for (size_t k = 0; k < count; ++k) {
+    if (n_points[k] > 0 && !xyz[k]) return fail(ctx, LGICP_E_INVALID, "xyz is null");
+    if (n_points[k] > (size_t)1 << 28) return fail(ctx, LGICP_E_INVALID, "cloud too large");
+    if (ctx->scans.count(keys[k]) || seen.count(keys[k])) continue;
+    seen[keys[k]] = 1;
+    in.push_back({keys[k], xyz[k], normals ? normals[k] : nullptr, n_points[k], stride_bytes / 4});
+  }
+  // sub-batches of at most 4M points: 128 MiB of pinned staging, 100 MiB of sort scratch
+  size_t first = 0;
+  std::vector<Keyframe> kfs;
+  while (first < in.size()) {
+    size_t last = first, pts = 0;
+    while (last < in.size() && (last == first || pts + in[last].n <= ((size_t)4 << 20))) pts += in[last++].n;
+    kfs.assign(last - first, Keyframe());
+    const int rc = register_keyframes(ctx, in.data() + first, last - first, kfs.data(), /*derive=*/true);
+    if (rc != LGICP_OK) {
+      // work of this sub-batch may be queued on buffers about to be freed
+      (void)hipStreamSynchronize(ctx->stream);
+      for (Keyframe& kf : kfs) kf.free_device();
+      ctx->reg.pending.erase(std::remove_if(ctx->reg.pending.begin(), ctx->reg.pending.end(),
+                                            [&](const Registry::Pending& p) {
+                                              return !ctx->scans.count(p.key);
+                                            }),
+                             ctx->reg.pending.end());
+      return rc;
+    }
+    for (size_t k = first; k < last; ++k) ctx->scans.emplace(in[k].key, kfs[k - first]);
+    first = last;
+  }
+  return (int)in.size();
+}
+
 int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const float* normals,
                        size_t n, size_t stride_bytes) {
+  return lgicp_add_keyframes(ctx, 1, &key, &xyz, normals ? &normals : nullptr, &n, stride_bytes);
+}
+
+int lgicp_wait_registered(lgicp_ctx* ctx) {
   if (!ctx) return LGICP_E_INVALID;
-  if (n > 0 && !xyz) return fail(ctx, LGICP_E_INVALID, "xyz is null");
-  if (stride_bytes < 12 || stride_bytes % 4) return fail(ctx, LGICP_E_INVALID, "bad stride");
-  if (n > (size_t)1 << 28) return fail(ctx, LGICP_E_INVALID, "cloud too large");
-  if (ctx->scans.count(key)) return 0;  // first wins (IcpLoopComputation.cc:380-385)
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-  Keyframe kf;
-  kf.n = (int)n;
-  kf.n_pad = std::max(NN_TILE, round_up((int)n, NN_TILE));
-  std::vector<float4> hx((size_t)kf.n_pad), hn(std::max<size_t>(n, 1));
-  const size_t sf = stride_bytes / 4;
-  for (size_t i = 0; i < n; ++i) {
-    hx[i] = make_float4(xyz[i * sf], xyz[i * sf + 1], xyz[i * sf + 2], 1.0f);
-    hn[i] = normals ? make_float4(normals[i * sf], normals[i * sf + 1], normals[i * sf + 2], 0.f)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  for (size_t i = n; i < (size_t)kf.n_pad; ++i)
-    hx[i] = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 1.0f);
-  kf.normals_missing = n > 0 && hn[0].x == 0.f && hn[0].y == 0.f && hn[0].z == 0.f;
-  HIP_TRY(ctx, hipMalloc((void**)&kf.d_xyz, sizeof(float4) * (size_t)kf.n_pad));
-  HIP_TRY(ctx, hipMalloc((void**)&kf.d_nrm, sizeof(float4) * std::max<size_t>(n, 1)));
-  HIP_TRY(ctx, hipMemcpy(kf.d_xyz, hx.data(), sizeof(float4) * (size_t)kf.n_pad,
-                         hipMemcpyHostToDevice));
-  if (n)
-    HIP_TRY(ctx, hipMemcpy(kf.d_nrm, hn.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
-  int rc = build_keyframe_index(ctx, &kf, xyz, sf);
-  if (rc == LGICP_OK) rc = build_keyframe_derived(ctx, &kf);
-  if (rc != LGICP_OK) {
-    kf.free_device();
-    return rc;
-  }
-  ctx->scans.emplace(key, kf);
-  return 1;
+  const int rc = flush_registrations(ctx);
+  if (rc != LGICP_OK) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LGICP_OK;
 }
 
 int lgicp_add_pose(lgicp_ctx* ctx, uint64_t key, const double q[4], const double t[3]) {
@@ -1330,6 +1287,11 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   if (n && (!cand || !out)) return fail(ctx, LGICP_E_INVALID, "null argument");
   const lgicp_config& cfg = ctx->cfg;
   HIP_TRY(ctx, hipSetDevice(cfg.device));
+  {
+    // keyframes registered since the last submit: their device work runs on the context's stream
+    const int rc = flush_registrations(ctx);
+    if (rc != LGICP_OK) return rc;
+  }
   reset_submit_stats(ctx->stats);
 
   // PerformAlignment's availability checks (IcpLoopComputation.cc:438-465)
@@ -1451,6 +1413,7 @@ extern "C" int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* sr
   int rc = lgicp_add_keyframe(ctx, ks, src_xyz, src_normals, n_src, 12);
   if (rc < 0) return rc;
   rc = lgicp_add_keyframe(ctx, kt, tgt_xyz, tgt_normals, n_tgt, 12);
+  if (rc >= 0) rc = flush_registrations(ctx);
   if (rc >= 0) {
     const double q[4] = {1, 0, 0, 0}, t[3] = {0, 0, 0};
     ctx->poses.emplace(ks, hm::pose_from_quat(q, t));

@@ -28,9 +28,17 @@ inline std::string g_create_error;
 
 struct CloudFeatures;
 
+struct DevBlock {  // one device allocation shared by the keyframes registered in one call
+  char* p = nullptr;
+  ~DevBlock() {
+    if (p) (void)hipFree(p);
+  }
+};
+
 struct Keyframe {
   int n = 0;
   int n_pad = 0;
+  std::shared_ptr<DevBlock> block;  // owns every d_* array below
   float4* d_xyz = nullptr;  // n_pad
   float4* d_nrm = nullptr;  // n
   // spatial index of the keyframe on its own (see CloudDev)
@@ -56,15 +64,10 @@ struct Keyframe {
   // parameters alone, and a keyframe shows up in many candidates over its lifetime)
   std::shared_ptr<CloudFeatures> features;
   void free_device() {
-    if (d_nrm_x == d_nrm) d_nrm_x = nullptr;
-    for (void* p : {(void*)d_xyz, (void*)d_nrm, (void*)d_order, (void*)d_sxyz, (void*)d_tmin,
-                    (void*)d_tmax, (void*)d_qorder, (void*)d_cov, (void*)d_nrm_x, (void*)d_rec})
-      if (p) (void)hipFree(p);
-    d_nrm_x = nullptr;
-    d_xyz = d_nrm = d_sxyz = d_tmin = d_tmax = nullptr;
+    block.reset();
+    d_xyz = d_nrm = d_sxyz = d_tmin = d_tmax = d_nrm_x = d_rec = nullptr;
     d_order = d_qorder = nullptr;
     d_cov = nullptr;
-    d_rec = nullptr;
   }
 };
 
@@ -87,6 +90,38 @@ struct DevBuf {  // grow-only device array
     p = nullptr;
     cap = 0;
   }
+};
+
+// One cloud handed to register_keyframes (host pointers, `stride_floats` floats between points;
+// nrm may be null: all-zero normals)
+struct KfInput {
+  uint64_t key;
+  const float* xyz;
+  const float* nrm;
+  size_t n;
+  size_t stride_floats;
+};
+
+// Buffers of keyframe registration, kept between calls (grow-only)
+struct Registry {
+  char* h_stage = nullptr;   // pinned: float4 points and normals of a batch on their way up
+  size_t stage_cap = 0;
+  char* h_tab = nullptr;     // pinned: per-keyframe tables of a batch
+  size_t tab_cap = 0;
+  char* h_const = nullptr;   // pinned, device-visible: CloudDev entries the NormalizePCloud kernel
+  size_t const_cap = 0;      // writes centroid / factor into, followed by their ids
+  size_t const_used = 0;
+  hipEvent_t ev_stage = nullptr;  // the last batch's uploads have left h_stage / h_tab
+  DevBuf<unsigned long long> d_keys[2];
+  DevBuf<int> d_ids[2];
+  DevBuf<unsigned> d_box;
+  DevBuf<char> d_tmp, d_tab;
+  struct Pending {
+    uint64_t key;
+    size_t slot;
+  };
+  std::vector<Pending> pending;  // keyframes whose constants have not been picked up yet
+  void destroy();
 };
 
 }  // namespace lgicp_detail
@@ -228,9 +263,7 @@ struct lgicp_ctx {
   int n_slots = 4;
   SlotThreads helpers;
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
-  DevBuf<IndexSegDev> d_isegs;   // for keyframe registration
-  DevBuf<CloudDev> d_reg_cloud;
-  DevBuf<int> d_reg_ids;
+  Registry reg;                  // keyframe registration
 };
 
 namespace lgicp_detail {
@@ -242,9 +275,12 @@ struct CloudFeatures {
   std::vector<float> xyz;     // [k][3]
   std::vector<float> feat;    // [k][33]
 };
-// builds the spatial index of a device-resident cloud treated as one segment
-int build_keyframe_index(lgicp_ctx* ctx, Keyframe* kf, const float* xyz, size_t stride_floats);
-int build_keyframe_derived(lgicp_ctx* ctx, Keyframe* kf);
+// Uploads `count` clouds and builds, on the device, their spatial index and (derive) what depends
+// on a keyframe alone: covariances from the normals, records, ExtractNormals, NormalizePCloud
+// constants.  Enqueued on the context's stream; flush_registrations() waits for it and picks the
+// constants up (the keyframes must be in ctx->scans under their keys by then).
+int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe* out, bool derive);
+int flush_registrations(lgicp_ctx* ctx);
 int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
                            CloudFeatures* out);
 int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,

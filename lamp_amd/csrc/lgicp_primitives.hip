@@ -61,40 +61,34 @@ int lgicp_nn_search(lgicp_ctx* ctx, const float T[16], const float* src_xyz, siz
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   hipStream_t st = ctx->stream;
   Dev d;
-  const int n_pad_t = std::max(NN_TILE, round_up((int)n_tgt, NN_TILE));
-  const int n_pad_s = std::max(NN_TILE, round_up((int)n_src, NN_TILE));
-  float4* d_src = upload_points(d, src_xyz, n_src, n_pad_s, 1.f);
-  float4* d_tgt = upload_points(d, tgt_xyz, n_tgt, n_pad_t, 1.f);
+  // both clouds go up like keyframes (padded float4 points + spatial index, nothing derived)
+  const KfInput in[2] = {{0, src_xyz, nullptr, n_src, 3}, {1, tgt_xyz, nullptr, n_tgt, 3}};
+  Keyframe kf[2];
+  {
+    const int rc = register_keyframes(ctx, in, 2, kf, /*derive=*/false);
+    if (rc != LGICP_OK) {
+      (void)hipStreamSynchronize(st);
+      return rc;
+    }
+  }
+  const int n_pad_t = kf[1].n_pad;
+  float4* d_src = kf[0].d_xyz;
   nnkey_t* d_keys = d.alloc<nnkey_t>(n_src);
   CloudDev* d_clouds = d.alloc<CloudDev>(2);
   PairDev* d_pair = d.alloc<PairDev>(1);
   PairState* d_state = d.alloc<PairState>(1);
   int32_t* d_idx = d.alloc<int32_t>(n_src);
   float* d_d2 = d.alloc<float>(n_src);
-  if (!d_src || !d_tgt || !d_keys || !d_clouds || !d_pair || !d_state || !d_idx || !d_d2)
+  if (!d_keys || !d_clouds || !d_pair || !d_state || !d_idx || !d_d2) {
+    (void)hipStreamSynchronize(st);
     return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  }
   CloudDev hc[2];
   std::memset(hc, 0, sizeof(hc));
-  hc[0].xyz = d_src, hc[0].n = (int)n_src, hc[0].n_pad = n_pad_s;
-  hc[1].xyz = d_tgt, hc[1].n = (int)n_tgt, hc[1].n_pad = n_pad_t;
-  struct IndexOwner {  // the index arrays of a cloud whose points belong to someone else
-    Keyframe kf;
-    ~IndexOwner() {
-      kf.d_xyz = kf.d_nrm = nullptr;
-      kf.free_device();
-    }
-  } is, it;
-  if (!ctx->nn_exhaustive) {
-    is.kf.n = (int)n_src, is.kf.d_xyz = d_src;
-    it.kf.n = (int)n_tgt, it.kf.d_xyz = d_tgt;
-    int rc = build_keyframe_index(ctx, &is.kf, src_xyz, 3);
-    if (rc == LGICP_OK) rc = build_keyframe_index(ctx, &it.kf, tgt_xyz, 3);
-    if (rc != LGICP_OK) return rc;
-    const Keyframe* k2[2] = {&is.kf, &it.kf};
-    for (int c = 0; c < 2; ++c) {
-      hc[c].sxyz = k2[c]->d_sxyz, hc[c].tmin = k2[c]->d_tmin, hc[c].tmax = k2[c]->d_tmax;
-      hc[c].qorder = k2[c]->d_qorder, hc[c].n_tiles = k2[c]->n_tiles, hc[c].n_q = k2[c]->n_q;
-    }
+  for (int c = 0; c < 2; ++c) {
+    hc[c].xyz = kf[c].d_xyz, hc[c].n = kf[c].n, hc[c].n_pad = kf[c].n_pad;
+    hc[c].sxyz = kf[c].d_sxyz, hc[c].tmin = kf[c].d_tmin, hc[c].tmax = kf[c].d_tmax;
+    hc[c].qorder = kf[c].d_qorder, hc[c].n_tiles = kf[c].n_tiles, hc[c].n_q = kf[c].n_q;
   }
   PairDev hp;
   std::memset(&hp, 0, sizeof(hp));

@@ -38,6 +38,17 @@ def partition_pairs(pairs, cloud_sizes, world):
     return out
 
 
+def shard_workload(work, world, rank):
+    """One rank's share of ONE candidate list (strong scaling: the reference's pair-level
+    parallelism, IcpLoopComputation.cc:327-365, across GPUs instead of pool threads): the indices
+    of the pairs rank `rank` aligns and the keys of the keyframes it has to register for them.
+    Every rank computes the same partition from the same list."""
+    sizes = {k: len(v[0]) for k, v in work.keyframes.items()}
+    mine = partition_pairs(work.pairs, sizes, world)[rank]
+    keys = sorted({k for i in mine for k in work.pairs[i]})
+    return mine, keys
+
+
 def pack_results(results, n=None):
     """lgicp_result array (the ctypes array lgicp_submit filled, or a list of results) ->
     [n, RESULT_WIDTH] float64 (keys are exact up to 2^53)."""

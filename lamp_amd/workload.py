@@ -5,8 +5,13 @@ sweep positions along a short trajectory inside a box-shaped room with box obsta
 cast against the axis-aligned geometry, range noise N(0, 0.02 m) is added along the ray, and
 the analytic normal of the hit face is stored (flipped toward the sensor).  A candidate pair is
 two keyframes of the same place seen from poses that differ by a known SE(3) offset
-(rotation <= 5 deg, translation <= 0.5 m).  Everything derives from one integer seed through
-numpy's PCG64, so the CPU box and the GPU box build identical clouds.
+(rotation <= 5 deg, translation <= 0.5 m).  In configuration C4 (global registration) every
+keyframe's own frame is additionally displaced from the pose its odometry reports by a rotation
+of up to 45 deg about a random axis and a translation of up to 2.5 m, so the two frames of a pair
+differ by up to 90 deg / 5 m while the registered poses know nothing of it: the odometry guess is
+wrong by that much and only a feature-based initialisation can recover the pair.  Everything
+derives from one integer seed through numpy's PCG64, so the CPU box and the GPU box build
+identical clouds.
 """
 import numpy as np
 
@@ -17,6 +22,7 @@ CONFIGS = {
     "C1": dict(pairs=1, points=10000, keyframes=2),
     "C2": dict(pairs=256, points=16384, keyframes=64),
     "C3": dict(pairs=1000, points=32768, keyframes=250),
+    "C4": dict(pairs=512, points=16384, keyframes=128),
     "C5": dict(pairs=10000, points=65536, keyframes=2000),
 }
 
@@ -43,6 +49,15 @@ def _quat_wxyz(R):
         q[1 + k] = (R[k, i] + R[i, k]) / s
     q = np.array(q)
     return q / np.linalg.norm(q)
+
+
+def pose_gap(Ta, Tb):
+    """(rotation angle in rad, translation norm in m) of Ta^-1 Tb, the angle from sin and cos
+    together (arccos of the trace alone cannot resolve small angles on float32 matrices)."""
+    dT = np.linalg.inv(np.asarray(Ta, np.float64)) @ np.asarray(Tb, np.float64)
+    R = dT[:3, :3]
+    s = 0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return float(np.arctan2(s, 0.5 * (np.trace(R) - 1.0))), float(np.linalg.norm(dT[:3, 3]))
 
 
 class Place:
@@ -123,7 +138,11 @@ class Workload:
     (key_from, key_to); truth: (key_from, key_to) -> 4x4 source->target transform"""
 
     def __init__(self, config="C2", pairs=None, points=None, keyframes=None, shard=0,
-                 pose_noise=(0.0, 0.0)):
+                 pose_noise=(0.0, 0.0), key_offset=0, frame_offset=None):
+        """shard: changes the seed (another batch of the same shape); key_offset: added to every
+        key, so that several workloads can live in one engine context; frame_offset: (max rotation
+        in deg, max translation in m) of every keyframe's frame against its registered pose
+        (default: C4 (45, 2.5), other configurations none)."""
         c = dict(CONFIGS[config])
         if pairs is not None:
             c["pairs"] = pairs
@@ -132,7 +151,10 @@ class Workload:
         if keyframes is not None:
             c["keyframes"] = keyframes
         self.config, self.n_pairs, self.n_points, self.n_keyframes = config, c["pairs"], c["points"], c["keyframes"]
-        cid = {"C1": 1, "C2": 2, "C3": 3, "C5": 5}[config]
+        cid = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5}[config]
+        if frame_offset is None:
+            frame_offset = (45.0, 2.5) if config == "C4" else (0.0, 0.0)
+        self.frame_offset = frame_offset
         self.seed = SEED_BASE + cid * (1 << 20) + shard * 4099
         rng = np.random.default_rng(self.seed)
         per_place = 8 if self.n_keyframes >= 8 else self.n_keyframes
@@ -152,13 +174,24 @@ class Workload:
                 d = rng.standard_normal(3)
                 t = base_t + d / np.linalg.norm(d) * rng.uniform(0, 0.25)
                 # keys are spaced by 10 so that no neighbour scan gets accumulated
-                k = 1000 + 10 * key
+                k = 1000 + 10 * key + key_offset
                 key += 1
-                self.keyframes[k] = make_keyframe(place, R, t, self.n_points, rng)
+                pts, nrms = make_keyframe(place, R, t, self.n_points, rng)
+                Rs, ts = R, t                      # the sensor's pose = what odometry reports
+                if frame_offset[0] > 0 or frame_offset[1] > 0:
+                    # the keyframe's own frame = sensor pose * D
+                    DR = _rot(rng.standard_normal(3), np.deg2rad(frame_offset[0]) * rng.random())
+                    dd = rng.standard_normal(3)
+                    Dt = dd / np.linalg.norm(dd) * frame_offset[1] * rng.random()
+                    pts = ((pts.astype(np.float64) - Dt) @ DR).astype(np.float32)
+                    nrms = (nrms.astype(np.float64) @ DR).astype(np.float32)
+                    R, t = Rs @ DR, ts + Rs @ Dt
+                self.keyframes[k] = (pts, nrms)
                 self.true_pose[k] = (R, t)
+                R_reg, t_reg = Rs, ts
                 # registered (odometry) pose = truth + optional drift
-                Rn = R @ _rot(rng.standard_normal(3), np.deg2rad(pose_noise[0]) * rng.random())
-                tn = t + pose_noise[1] * (rng.random(3) * 2 - 1)
+                Rn = R_reg @ _rot(rng.standard_normal(3), np.deg2rad(pose_noise[0]) * rng.random())
+                tn = t_reg + pose_noise[1] * (rng.random(3) * 2 - 1)
                 self.poses[k] = (_quat_wxyz(Rn), tn)
                 place_of[k] = pl
         keys = sorted(self.keyframes)
@@ -176,9 +209,16 @@ class Workload:
             T[:3, 3] = Rb.T @ (ta - tb)
             self.truth[(a, b)] = T
 
-    def register(self, ctx):
-        for k, (xyz, nrm) in self.keyframes.items():
-            ctx.add_keyframe(k, xyz, nrm)
+    def register(self, ctx, batched=True):
+        """keyframes and poses into the engine: one lgicp_add_keyframes call (batched), or one
+        lgicp_add_keyframe call per scan as the reference's KeyedScanCallback receives them"""
+        keys = list(self.keyframes)
+        if batched:
+            ctx.add_keyframes(keys, [self.keyframes[k][0] for k in keys],
+                              [self.keyframes[k][1] for k in keys])
+        for k in keys:
+            if not batched:
+                ctx.add_keyframe(k, *self.keyframes[k])
             ctx.add_pose(k, *self.poses[k])
 
     def candidates(self):
