@@ -106,8 +106,12 @@ def cpu_baseline_c4(work, n_sample, cores, harris_radius):
         return bool(r["converged"])
 
     t0 = time.perf_counter()
+    st = []
     with ThreadPoolExecutor(max_workers=min(cores, len(pairs))) as ex:
-        st = list(ex.map(one, pairs))
+        for k, ok in enumerate(ex.map(one, pairs)):
+            st.append(ok)
+            print(f"[bench] cpu baseline pair {k + 1}/{len(pairs)} after {time.perf_counter() - t0:.1f} s",
+                  file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     return {"value": len(pairs) / dt, "unit": "pairs/s", "cores": min(cores, len(pairs)), "kind": "port",
             "host_cpus_visible": os.cpu_count(),
@@ -203,6 +207,13 @@ def main():
                     help="use the exhaustive 1-NN kernel instead of the pruned one")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
+
+    def progress(what):
+        # a line on stderr per phase: long configurations (C4, C5) stay visibly alive
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"[bench {time.perf_counter() - t_start:7.1f} s] {what}", file=sys.stderr, flush=True)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -252,6 +263,7 @@ def main():
         reg_s += register(ctx, w, keys)
         reg_kf += len(keys)
     packed = [ctx.pack_candidates(c) for c in cand_lists]
+    progress(f"{reg_kf} keyframes registered in {reg_s:.3f} s")
 
     gatherer = None
     if dist is not None:
@@ -286,7 +298,10 @@ def main():
         res = []
         for i in range(first, first + n_steps):
             s0 = c.stats()
+            t_s = time.perf_counter()
             res.append(step(i, None if c is ctx else c, pk))
+            if time.perf_counter() - t_s > 1.0:
+                progress(f"step {i - first + 1}/{n_steps}: {time.perf_counter() - t_s:.1f} s")
             s1 = c.stats()
             acc["nn_ms"] += s1.nn_ms
             acc["nn_launches"] += s1.nn_launches - s0.nn_launches
@@ -303,6 +318,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+        progress(f"warm-up {i + 1}/{args.warmup}")
     barrier()
     t0 = time.perf_counter()
     acc, stage, results = collect(ctx, args.steps, args.warmup)
@@ -330,6 +346,7 @@ def main():
                 ang, te = pose_gap(works[b].truth[(a, bb)], np.array(r.T_icp, np.float64).reshape(4, 4))
                 terr.append(te), rerr.append(ang)
 
+    progress(f"timed region: {dt:.3f} s for {args.steps} steps")
     # ---- a batch never seen before: registration + submit ----------------------------------------
     cold = None
     if not args.no_cold and not strong and world == 1:
@@ -345,6 +362,7 @@ def main():
         cold = {"keyframes": len(keys_c), "pairs": len(wc.pairs), "registration_ms": 1e3 * (t_b - t_a),
                 "submit_ms": 1e3 * (t_c - t_b), "value": len(wc.pairs) / (t_c - t_a)}
 
+    progress("cold batch done" if cold else "no cold batch")
     # ---- exclusive phase: the same batches on one stream -----------------------------------------
     excl = None
     if not args.no_exclusive_phase and rank == 0 and not args.exhaustive:
@@ -363,6 +381,7 @@ def main():
         finally:
             c1.close()
 
+    progress("exclusive phase done" if excl else "no exclusive phase")
     if rank == 0:
         value = total_pairs_per_batch * args.steps / dt
         kernel_name = "lgicp::nn_kernel<4>" if args.exhaustive else "lgicp::nn_pruned_kernel"

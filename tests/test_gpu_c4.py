@@ -1,0 +1,117 @@
+"""Configuration C4: FPFH + TEASER++ (and SAC-IA) global registration of pairs whose frames are up
+to 90 degrees / 5 m apart while their registered odometry poses know nothing of it
+(IcpLoopComputation::GetTeaserInitialAlignment, loop_closure/src/IcpLoopComputation.cc:949-1081;
+GetSacInitialAlignment :650-705).  Four 16k-point pairs per method against the CPU oracle, then a
+larger batch checked through a property: the recovered pose is the synthetic truth.
+
+TEASER++ is not in the reference tree and its test there is commented out
+(test_loop_computation.cc:101-123): the oracle restates the publication, parity unpinned."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RADIUS = 0.5   # Harris radius the C4 bench line uses on these ring-sampled 16k-point scans
+
+
+def _odom_guess(work, a, b):
+    p21 = O.pose_between(O.pose_from_quat(*work.poses[b]), O.pose_from_quat(*work.poses[a]))
+    g = np.eye(4, dtype=np.float32)
+    g[:3, :3] = np.array(p21.R).reshape(3, 3)
+    g[:3, 3] = np.array(p21.t)
+    return g
+
+
+def _submit(work, method, radius=RADIUS, **kw):
+    from lamp_amd import capi
+    c = capi.Context(init_method=method, harris_radius=radius, transform_thresholding=0, **kw)
+    try:
+        work.register(c)
+        return [capi.result_to_dict(r) for r in c.submit(work.candidates())]
+    finally:
+        c.close()
+
+
+def test_c4_workload_has_large_misalignment():
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=64, keyframes=16)
+    rot, tr, guess_err = [], [], []
+    for a, b in work.pairs:
+        T = work.truth[(a, b)]
+        ang, te = O.pose_gap(np.eye(4), T)
+        rot.append(ang), tr.append(te)
+        guess_err.append(O.pose_gap(_odom_guess(work, a, b), T))
+    assert np.rad2deg(max(rot)) <= 90.0 + 1e-6 and max(tr) <= 5.0 + 0.6
+    assert np.rad2deg(np.median(rot)) > 15.0 and np.median(tr) > 0.8
+    # the odometry guess is off by about as much: nothing GICP's 0.5 m gate could bridge
+    assert np.median([g[0] for g in guess_err]) > np.deg2rad(15.0)
+    assert np.median([g[1] for g in guess_err]) > 0.8
+
+
+def test_c4_teaser_pairs_match_oracle():
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=4, keyframes=4)
+    assert work.n_points == 16384
+    res = _submit(work, capi.INIT_TEASERPP)
+    for d, (a, b) in zip(res, work.pairs):
+        src, sn = work.keyframes[a]
+        tgt, tn = work.keyframes[b]
+        g = _odom_guess(work, a, b)
+        T0, used, nm, nc = O.teaser_initial_alignment(src, sn, tgt, tn, harris_radius=RADIUS, guess=g)
+        assert nm > 10
+        assert np.allclose(d["T_init"], T0, atol=1e-6), (a, b)
+        assert d["init_fitness"] == (nc if used else 0)
+        ref = O.gicp_align(O.base_gicp_params(solver=O.SOLVER_GN), src, sn, tgt, tn, guess=T0)
+        assert d["converged"] == ref["converged"]
+        ang, te = O.pose_gap(ref["T"], d["T_icp"])
+        assert ang < 1e-4 and te < 1e-4, (a, b, ang, te)
+        assert d["iterations"] == ref["iterations"]
+
+
+def test_c4_sac_pairs_match_oracle():
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=4, keyframes=4)
+    res = _submit(work, capi.INIT_FEATURES)
+    for d, (a, b) in zip(res, work.pairs):
+        src, sn = work.keyframes[a]
+        tgt, tn = work.keyframes[b]
+        g = _odom_guess(work, a, b)
+        T0, fit0, _ = O.sac_initial_alignment(src, sn, tgt, tn, harris_radius=RADIUS, iterations=500,
+                                              guess=g, seed=capi.pair_seed(a, b))
+        assert np.allclose(d["T_init"], T0, atol=1e-5), (a, b)
+        assert abs(d["init_fitness"] - fit0) <= 1e-5 * max(fit0, 1e-12)
+        if not fit0 < 32.0:      # sac_fitness_score_threshold of the base block
+            assert d["status"] == capi.PAIR_INIT_REJECTED
+            continue
+        ref = O.gicp_align(O.base_gicp_params(solver=O.SOLVER_GN), src, sn, tgt, tn, guess=T0)
+        assert d["converged"] == ref["converged"]
+        ang, te = O.pose_gap(ref["T"], d["T_icp"])
+        assert ang < 1e-4 and te < 1e-4, (a, b, ang, te)
+
+
+@pytest.mark.parametrize("method,min_recovered", [("teaser", 0.8), ("sac", 0.75)])
+def test_c4_batch_recovers_the_true_poses(method, min_recovered):
+    """Size-independent property on a larger batch (64 pairs over 16 keyframes): the pose that
+    comes out is the synthetic truth, although the guess is wrong by tens of degrees and metres."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=64, keyframes=16)
+    # Harris radius 0.3: measured 58 (TEASER++) and 56 (SAC-IA) of these 64 pairs recovered; 0.5, the
+    # radius of the oracle comparisons above, recovers 50 and 52 at a fifth of the matches
+    res = _submit(work, capi.INIT_TEASERPP if method == "teaser" else capi.INIT_FEATURES, radius=0.3)
+    good = 0
+    for d, (a, b) in zip(res, work.pairs):
+        ang, te = O.pose_gap(work.truth[(a, b)], d["T_icp"])
+        good += d["status"] == 0 and ang < 0.02 and te < 0.1
+    assert good >= min_recovered * len(work.pairs), (method, good)
+    # and GICP alone, from the odometry guess, recovers next to none of them
+    if method == "sac":
+        return
+    lost = _submit(work, capi.INIT_ODOMETRY)
+    n_lost = sum(not (d["status"] == 0 and O.pose_gap(work.truth[p], d["T_icp"])[1] < 0.1)
+                 for d, p in zip(lost, work.pairs))
+    assert n_lost >= 0.8 * len(work.pairs), n_lost

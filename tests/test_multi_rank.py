@@ -65,6 +65,34 @@ def _worker(rank, world, port, out_path):
             np.save(out_path + f".fixed{call}.npy", allr.copy())
         else:
             assert allr is None
+    # strong scaling, as `bench.py --mode strong` runs it: ONE candidate list cut over the ranks,
+    # every rank holds only the keyframes its own pairs touch, variable record counts per rank
+    import torch
+    from lamp_amd.sharding import shard_workload
+    one = Workload("C3", pairs=7, points=1200, keyframes=6)
+    mine, keys = shard_workload(one, world, rank)
+    held = {k: one.keyframes[k] for k in keys}          # what this rank would register
+    recs = []
+    for i in mine:
+        a, b = one.pairs[i]
+        src, sn = held[a]                               # KeyError = a keyframe the shard lacks
+        tgt, tn = held[b]
+        ref = O.perform_alignment(O.base_icp_params(init_method=O.INIT_IDENTITY, solver=O.SOLVER_GN),
+                                  src, sn, tgt, tn, src, tn, O.pose_from_quat([1, 0, 0, 0], [0, 0, 0]))
+        r = capi.Result()
+        r.key_from, r.key_to, r.status, r.iterations = a, b, ref["status"], ref["iterations"]
+        r.fitness = ref["fitness"]
+        recs.append(r)
+    t = torch.zeros(world, dtype=torch.int64)
+    t[rank] = len(mine)
+    dist.all_reduce(t)
+    counts = [int(v) for v in t]
+    gs = RecordGatherer(dist, rank, world, counts, torch.device("cpu"))
+    for call in range(2):                               # the same buffers on every step
+        allr = gs.gather(pack_results(recs) if recs else np.zeros((0, RESULT_WIDTH)))
+        if rank == 0:
+            np.save(out_path + f".strong{call}.npy", allr.copy())
+            np.save(out_path + ".strong_counts.npy", np.array(counts))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,3 +114,12 @@ def test_two_rank_gloo_gather(tmp_path):
         fixed = np.load(out + f".fixed{call}.npy")
         assert fixed.shape == (6, 128)
         assert fixed[:, 0].tolist() == [100.0 * call + 10.0 * r + k for r in range(2) for k in range(3)]
+    # strong mode: every pair of the one list exactly once, whatever the per-rank counts were
+    one = Workload("C3", pairs=7, points=1200, keyframes=6)
+    counts = np.load(out + ".strong_counts.npy")
+    assert counts.sum() == 7 and len(counts) == 2
+    for call in range(2):
+        rec = np.load(out + f".strong{call}.npy")
+        assert rec.shape == (7, 128)
+        assert sorted((int(r[0]), int(r[1])) for r in rec) == sorted(one.pairs)
+        assert np.all(rec[:, 2] == 0) and np.all(rec[:, 4] > 0)
