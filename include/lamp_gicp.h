@@ -240,8 +240,10 @@ int lgicp_compute_ap(lgicp_ctx* ctx, const float* query_xyz, size_t n_query,
 int lgicp_fpfh(lgicp_ctx* ctx, const float* surface_xyz, const float* surface_normals, size_t n,
                const float* keypoints_xyz, size_t n_key, double radius, float* out);
 
-/* lamp_utils::ComputeKeypoints with normals (PointCloudUtils.cc:78-96): Harris3D keypoints with
- * the context's harris_* parameters.  Writes up to `capacity` indices (ascending) and the total
+/* lamp_utils::ComputeKeypoints (PointCloudUtils.cc:61-96): Harris3D keypoints with the context's
+ * harris_* parameters.  normals != NULL is the overload the path uses (:78-96); normals == NULL is
+ * the overload without normals (:61-76), where pcl::HarrisKeypoint3D estimates them itself over a
+ * radius search with the Harris radius.  Writes up to `capacity` indices (ascending) and the total
  * count. */
 int lgicp_harris_keypoints(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
                            int32_t* idx_out, size_t capacity, size_t* count);

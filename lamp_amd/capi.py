@@ -300,12 +300,14 @@ class Context:
                                      float(radius), _ptr(out)))
         return out
 
-    def harris_keypoints(self, xyz, normals):
-        x, nn = _f32(xyz).reshape(-1, 3), _f32(normals).reshape(-1, 3)
+    def harris_keypoints(self, xyz, normals=None):
+        """normals=None: the ComputeKeypoints overload that estimates them over the Harris radius"""
+        x = _f32(xyz).reshape(-1, 3)
+        nn = None if normals is None else _f32(normals).reshape(-1, 3)
         idx = np.empty(len(x), np.int32)
         cnt = C.c_size_t()
-        self._check(lib().lgicp_harris_keypoints(self._h, _ptr(x), _ptr(nn), len(x), _ptr(idx),
-                                                 len(idx), C.byref(cnt)))
+        self._check(lib().lgicp_harris_keypoints(self._h, _ptr(x), None if nn is None else _ptr(nn),
+                                                 len(x), _ptr(idx), len(idx), C.byref(cnt)))
         return idx[: cnt.value].copy()
 
     def sac_initial_alignment(self, src, src_n, tgt, tgt_n, guess=None):

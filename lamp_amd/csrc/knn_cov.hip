@@ -60,6 +60,117 @@ __device__ void compute_roots(const float m[9], float roots[3]) {
   if (roots[0] <= 0.0f) roots2(c2, c1, roots);
 }
 
+// pcl::NormalEstimation::computePointNormal from the single-pass float sums of `count` points
+// (xx xy xz yy yz zz x y z): covariance, smallest eigenvector by the closed-form roots + row cross
+// products of pcl::eigen33, curvature, flip towards the viewpoint (0, 0, 0).  Returns
+// (nx, ny, nz, curvature).
+__device__ float4 normal_from_moments(float accu[9], int count, float qx, float qy, float qz) {
+  const float fk = (float)count;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) accu[e] /= fk;
+  float cov[9];
+  cov[0] = accu[0] - accu[6] * accu[6];
+  cov[1] = cov[3] = accu[1] - accu[6] * accu[7];
+  cov[2] = cov[6] = accu[2] - accu[6] * accu[8];
+  cov[4] = accu[3] - accu[7] * accu[7];
+  cov[5] = cov[7] = accu[4] - accu[7] * accu[8];
+  cov[8] = accu[5] - accu[8] * accu[8];
+  float scale = 0.f;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) scale = fabsf(cov[e]) > scale ? fabsf(cov[e]) : scale;
+  if (scale <= 1.17549435e-38f) scale = 1.0f;
+  float sm[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) sm[e] = cov[e] / scale;
+  float roots[3];
+  compute_roots(sm, roots);
+  const float ev = roots[0] * scale;
+  sm[0] -= roots[0];
+  sm[4] -= roots[0];
+  sm[8] -= roots[0];
+  const float v1[3] = {sm[1] * sm[5] - sm[2] * sm[4], sm[2] * sm[3] - sm[0] * sm[5], sm[0] * sm[4] - sm[1] * sm[3]};
+  const float v2[3] = {sm[1] * sm[8] - sm[2] * sm[7], sm[2] * sm[6] - sm[0] * sm[8], sm[0] * sm[7] - sm[1] * sm[6]};
+  const float v3[3] = {sm[4] * sm[8] - sm[5] * sm[7], sm[5] * sm[6] - sm[3] * sm[8], sm[3] * sm[7] - sm[4] * sm[6]};
+  const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+  const float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+  const float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+  float nx, ny, nz, len;
+  if (l1 >= l2 && l1 >= l3)
+    nx = v1[0], ny = v1[1], nz = v1[2], len = l1;
+  else if (l2 >= l1 && l2 >= l3)
+    nx = v2[0], ny = v2[1], nz = v2[2], len = l2;
+  else
+    nx = v3[0], ny = v3[1], nz = v3[2], len = l3;
+  const float r = sqrtf(len);
+  nx /= r, ny /= r, nz /= r;
+  const float eig_sum = cov[0] + cov[4] + cov[8];
+  const float curv = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
+  const float vx = 0.f - qx, vy = 0.f - qy, vz = 0.f - qz;
+  const float cos_theta = vx * nx + vy * ny + vz * nz;
+  if (cos_theta < 0.f) nx *= -1.f, ny *= -1.f, nz *= -1.f;
+  return make_float4(nx, ny, nz, curv);
+}
+
+// The normals pcl::HarrisKeypoint3D estimates for itself when none are handed in (the
+// lamp_utils::ComputeKeypoints overload without normals, lamp_utils/src/PointCloudUtils.cc:61-76):
+// pcl::NormalEstimation over a radius search.  One lane per point, the cloud streaming through
+// LDS; neighbours = points at squared distance < r2 (FLANN's strict test, the point itself
+// included) summed in ascending index (PCL visits them by ascending distance, so the last float
+// bits can differ); fewer than 3 neighbours give a NaN normal.
+static constexpr int NR_TILE = 512;
+__global__ __launch_bounds__(256) void normals_radius_kernel(const float4* __restrict__ xyz, int n,
+                                                             float r2, float4* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float tile[3 * NR_TILE];
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  float4 p = make_float4(__builtin_nanf(""), 0, 0, 0);
+  if (i < n) p = xyz[i];
+  float accu[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int count = 0;
+  for (int base = 0; base < n; base += NR_TILE) {
+    __syncthreads();
+    for (int j = tid; j < NR_TILE; j += 256) {
+      float4 q = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 0);
+      if (base + j < n) q = xyz[base + j];
+      tile[j] = q.x;
+      tile[NR_TILE + j] = q.y;
+      tile[2 * NR_TILE + j] = q.z;
+    }
+    __syncthreads();
+    const int jend = min(NR_TILE, n - base);
+    for (int j = 0; j < jend; ++j) {
+      const float x = tile[j], y = tile[NR_TILE + j], z = tile[2 * NR_TILE + j];
+      const float dx = p.x - x, dy = p.y - y, dz = p.z - z;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      if (!(d2 < r2)) continue;
+      accu[0] += x * x;
+      accu[1] += x * y;
+      accu[2] += x * z;
+      accu[3] += y * y;
+      accu[4] += y * z;
+      accu[5] += z * z;
+      accu[6] += x;
+      accu[7] += y;
+      accu[8] += z;
+      ++count;
+    }
+  }
+  if (i >= n) return;
+  const float nan = __builtin_nanf("");
+  float4 res = make_float4(nan, nan, nan, nan);
+  if (count >= 3 && isfinite(p.x) && isfinite(p.y) && isfinite(p.z))
+    res = normal_from_moments(accu, count, p.x, p.y, p.z);
+  out[i] = res;
+}
+
+hipError_t launch_normals_radius(const float4* xyz, int n, float r2, float4* normals_curv,
+                                 hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(normals_radius_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, xyz, n, r2,
+                     normals_curv);
+  return hipGetLastError();
+}
+
 // MODE 0: GICP covariance (gicp.hpp:83-155) into out_d[n][6].
 // MODE 1: surface normal + curvature of pcl::NormalEstimation (lamp_utils::ComputeNormals,
 //         lamp_utils/include/lamp_utils/PointCloudUtils.h:38-62) into out_f[n] = (nx, ny, nz, curvature):
@@ -156,50 +267,7 @@ __global__ __launch_bounds__(NN_THREADS) void cov_knn_kernel(const float4* __res
           accu[8] += p.z;
         }
       }
-      const float fk = (float)k;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) accu[e] /= fk;
-      float cov[9];
-      cov[0] = accu[0] - accu[6] * accu[6];
-      cov[1] = cov[3] = accu[1] - accu[6] * accu[7];
-      cov[2] = cov[6] = accu[2] - accu[6] * accu[8];
-      cov[4] = accu[3] - accu[7] * accu[7];
-      cov[5] = cov[7] = accu[4] - accu[7] * accu[8];
-      cov[8] = accu[5] - accu[8] * accu[8];
-      float scale = 0.f;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) scale = fabsf(cov[e]) > scale ? fabsf(cov[e]) : scale;
-      if (scale <= 1.17549435e-38f) scale = 1.0f;
-      float sm[9];
-#pragma unroll
-      for (int e = 0; e < 9; ++e) sm[e] = cov[e] / scale;
-      float roots[3];
-      compute_roots(sm, roots);
-      const float ev = roots[0] * scale;
-      sm[0] -= roots[0];
-      sm[4] -= roots[0];
-      sm[8] -= roots[0];
-      const float v1[3] = {sm[1] * sm[5] - sm[2] * sm[4], sm[2] * sm[3] - sm[0] * sm[5], sm[0] * sm[4] - sm[1] * sm[3]};
-      const float v2[3] = {sm[1] * sm[8] - sm[2] * sm[7], sm[2] * sm[6] - sm[0] * sm[8], sm[0] * sm[7] - sm[1] * sm[6]};
-      const float v3[3] = {sm[4] * sm[8] - sm[5] * sm[7], sm[5] * sm[6] - sm[3] * sm[8], sm[3] * sm[7] - sm[4] * sm[6]};
-      const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
-      const float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
-      const float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
-      float nx, ny, nz, len;
-      if (l1 >= l2 && l1 >= l3)
-        nx = v1[0], ny = v1[1], nz = v1[2], len = l1;
-      else if (l2 >= l1 && l2 >= l3)
-        nx = v2[0], ny = v2[1], nz = v2[2], len = l2;
-      else
-        nx = v3[0], ny = v3[1], nz = v3[2], len = l3;
-      const float r = sqrtf(len);
-      nx /= r, ny /= r, nz /= r;
-      const float eig_sum = cov[0] + cov[4] + cov[8];
-      const float curv = eig_sum != 0.f ? fabsf(ev / eig_sum) : 0.f;
-      const float vx = 0.f - qx, vy = 0.f - qy, vz = 0.f - qz;
-      const float cos_theta = vx * nx + vy * ny + vz * nz;
-      if (cos_theta < 0.f) nx *= -1.f, ny *= -1.f, nz *= -1.f;
-      res = make_float4(nx, ny, nz, curv);
+      res = normal_from_moments(accu, k, qx, qy, qz);
     }
     out_f[i] = res;
     return;

@@ -178,6 +178,11 @@ hipError_t launch_cov_knn(const float4* xyz, int n, int n_pad, int k, double eps
 hipError_t launch_normals_knn(const float4* xyz, int n, int n_pad, int k, float4* normals_curv,
                               hipStream_t stream);
 
+// pcl::NormalEstimation with a radius search (what pcl::HarrisKeypoint3D runs when it is given no
+// normals): normals_curv[n] = (nx, ny, nz, curvature), NaN with fewer than 3 neighbours
+hipError_t launch_normals_radius(const float4* xyz, int n, float r2, float4* normals_curv,
+                                 hipStream_t stream);
+
 // FPFH at n_key keypoints over a surface of n points (radius^2 = r2); need[n], spfh[n*33]
 // are scratch, out is [n_key][33]
 hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float4* keys, int n_key,

@@ -259,15 +259,21 @@ int lgicp_fpfh(lgicp_ctx* ctx, const float* surface_xyz, const float* surface_no
 
 int lgicp_harris_keypoints(lgicp_ctx* ctx, const float* xyz, const float* normals, size_t n,
                            int32_t* idx_out, size_t capacity, size_t* count) {
-  if (!ctx || !count || (n && (!xyz || !normals)) || (capacity && !idx_out))
+  if (!ctx || !count || (n && !xyz) || (capacity && !idx_out))
     return fail(ctx, LGICP_E_INVALID, "null argument");
   *count = 0;
   if (n == 0) return LGICP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   Dev d;
   float4* d_x = upload_points(d, xyz, n, (int)n, 1.f);
-  float4* d_n = upload_points(d, normals, n, (int)n, 0.f);
+  float4* d_n = normals ? upload_points(d, normals, n, (int)n, 0.f) : d.alloc<float4>(n);
   if (!d_x || !d_n) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  if (!normals) {
+    // the overload without normals (PointCloudUtils.cc:61-76): HarrisKeypoint3D estimates them
+    // itself over a radius search with the Harris radius
+    const float r2 = (float)(ctx->cfg.harris_radius * ctx->cfg.harris_radius);
+    HIP_TRY(ctx, launch_normals_radius(d_x, (int)n, r2, d_n, ctx->stream));
+  }
   CloudFeatures cf;
   const int rc = compute_cloud_features(ctx, d_x, d_n, (int)n, &cf);
   if (rc != LGICP_OK) return rc;

@@ -165,6 +165,10 @@ void lo_point_normal(const float* xyz, const int32_t* idx, int k, const float* q
                      float* curvature);
 void lo_compute_normals(const float* xyz, int n, int k, float* normals, float* curvature,
                         int threads);
+/* pcl::NormalEstimation over a radius search: what pcl::HarrisKeypoint3D computes for itself in
+ * the lamp_utils::ComputeKeypoints overload without normals (PointCloudUtils.cc:61-76) */
+void lo_compute_normals_radius(const float* xyz, int n, double radius, float* normals,
+                               float* curvature);
 /* lamp_utils::ExtractNormals (PointCloudUtils.cc:17-35) */
 void lo_extract_normals(const float* xyz, const float* stored, int n, int k, float* normals,
                         int threads);

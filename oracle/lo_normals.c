@@ -163,6 +163,34 @@ void lo_compute_normals(const float* xyz, int n, int k, float* normals, float* c
   lo_kdtree_free(t);
 }
 
+/* The normals pcl::HarrisKeypoint3D estimates for itself when none are handed in (the
+ * lamp_utils::ComputeKeypoints overload without normals, lamp_utils/src/PointCloudUtils.cc:61-76):
+ * pcl::NormalEstimation over a radius search with the Harris radius.  Neighbours = points with
+ * squared distance < radius^2 (FLANN's strict test, the point itself included), summed in
+ * ascending index (PCL visits them by ascending distance: last float bits may differ); fewer
+ * than 3 neighbours give a NaN normal. */
+void lo_compute_normals_radius(const float* xyz, int n, double radius, float* normals,
+                               float* curvature) {
+  if (n <= 0) return;
+  const float r2 = (float)(radius * radius);
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const float* q = xyz + 3 * (size_t)i;
+    int k = 0;
+    if (isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]))
+      for (int j = 0; j < n; ++j) {
+        const float* p = xyz + 3 * (size_t)j;
+        const float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < r2) idx[k++] = j;
+      }
+    float c;
+    lo_point_normal(xyz, idx, k, q, normals + 3 * (size_t)i, &c);
+    if (curvature) curvature[i] = c;
+  }
+  free(idx);
+}
+
 /* lamp_utils::ExtractNormals (PointCloudUtils.cc:17-35): the stored normals, unless the first
  * point's normal is all zero, in which case every normal is recomputed */
 void lo_extract_normals(const float* xyz, const float* stored, int n, int k, float* normals,

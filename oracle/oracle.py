@@ -307,7 +307,21 @@ def fpfh(surface_xyz, surface_normals, keypoints_xyz, radius):
     return out
 
 
+def compute_normals_radius(xyz, radius):
+    """pcl::NormalEstimation over a radius search (HarrisKeypoint3D's own normals)."""
+    xyz = _f32(xyz)
+    nrm = np.empty((len(xyz), 3), np.float32)
+    cur = np.empty(len(xyz), np.float32)
+    lib().lo_compute_normals_radius(_p(xyz, C.c_float), len(xyz), C.c_double(radius),
+                                    _p(nrm, C.c_float), _p(cur, C.c_float))
+    return nrm, cur
+
+
 def harris_keypoints(xyz, normals, radius, threshold=5e-9, nms=True):
+    """normals=None: the ComputeKeypoints overload without normals (PointCloudUtils.cc:61-76)."""
+    xyz = _f32(xyz)
+    if normals is None:
+        normals = compute_normals_radius(xyz, radius)[0]
     xyz, normals = _f32(xyz), _f32(normals)
     idx = np.empty(len(xyz), np.int32)
     resp = np.empty(len(xyz), np.float32)

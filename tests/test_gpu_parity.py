@@ -380,6 +380,43 @@ def test_harris_keypoints_match_oracle():
             c.close()
 
 
+def test_harris_keypoints_without_normals_match_oracle():
+    """The ComputeKeypoints overload without normals (PointCloudUtils.cc:61-76): HarrisKeypoint3D's
+    own radius-search normals, then the same detector.  On the
+    reference's corner fixture (test_point_cloud_utils.cc:114-133) the keypoints are among the
+    three coordinates that test pins."""
+    from lamp_amd import capi
+    c = capi.Context(harris_radius=1.0)
+    try:
+        corner, _ = F.generate_corner()
+        # the three pinned points tie in exact arithmetic; which of them survive the suppression
+        # hangs on the last bits of atan2f / cosf (device and host libm differ there), so only
+        # membership is compared on this fixture
+        got = c.harris_keypoints(corner)
+        assert 1 <= len(got) <= 3
+        pinned = {(0.3, 0.3, 0.0), (0.3, 0.0, 0.3), (0.0, 0.3, 0.3)}
+        assert {tuple(np.round(corner[i].astype(np.float64), 5).tolist()) for i in got} <= pinned
+    finally:
+        c.close()
+    for radius, n, seed in [(0.3, 3000, 44), (0.5, 5000, 45)]:
+        c = capi.Context(harris_radius=radius)
+        try:
+            xyz, _ = F.random_room_scan(n, seed)
+            ref, _ = O.harris_keypoints(xyz, None, radius)
+            got = c.harris_keypoints(xyz)
+            # the estimated normals carry the last-bit differences of atan2f / cosf between the
+            # device and the host's libm: a response sitting on the threshold or tying with a
+            # neighbour may fall either way, everything else is the same index set
+            diff = sorted(set(got.tolist()) ^ set(ref.tolist()))
+            assert len(ref) > 0 and len(diff) <= max(1, len(ref) // 10), (radius, len(got), len(ref))
+            # ... and only marginal ones do: responses within float noise (the response formula
+            # cancels 0.04 against 0.04 trace^2, quantum 3.7e-9) of the 5e-9 threshold
+            resp = O.harris_response(xyz, O.compute_normals_radius(xyz, radius)[0], radius)
+            assert all(abs(resp[i]) < 1e-6 for i in diff), [(i, float(resp[i])) for i in diff]
+        finally:
+            c.close()
+
+
 def test_sac_initial_alignment_reference_corner_case():
     """TestSacInitialAlign (test_loop_computation.cc:78-104) through the C ABI."""
     from lamp_amd import capi

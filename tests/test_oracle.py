@@ -381,3 +381,27 @@ def test_compute_normals_room():
     assert np.all((nrm * -xyz).sum(1) >= -1e-6)              # flipped towards the origin
     assert np.median(np.abs((nrm * true_n).sum(1))) > 0.99
     assert np.all((cur >= 0) & (cur <= 1 / 3 + 1e-5))
+
+
+def test_harris_keypoints_without_normals_reference_corner():
+    """lamp_utils/test/test_point_cloud_utils.cc:114-133 pins three keypoints on the corner for the
+    ComputeKeypoints overload without normals: (0.3,0.3,0), (0.3,0,0.3), (0,0.3,0.3), the three
+    images of one point under the corner's symmetry.  Their responses are equal in exact
+    arithmetic and all three survive PCL's non-maxima suppression only because PCL's float sums
+    come out bit-identical for them; that depends on the order in which FLANN's radius search
+    hands back equidistant grid neighbours, which the reference tree does not determine.  With
+    neighbours summed in ascending index the three responses agree to 3e-8 and are the three
+    largest of the cloud; the suppression then keeps the one(s) ahead in the last bits."""
+    corner, _ = F.generate_corner()
+    nrm, _ = O.compute_normals_radius(corner, 1.0)
+    resp = O.harris_response(corner, nrm, 1.0)
+    top3 = np.argsort(-resp)[:3]
+    got = {tuple(np.round(corner[i].astype(np.float64), 5).tolist()) for i in top3}
+    assert got == {(0.3, 0.3, 0.0), (0.3, 0.0, 0.3), (0.0, 0.3, 0.3)}
+    assert resp[top3].max() - resp[top3].min() < 3e-8 and resp[top3].min() > 5e-9
+    assert np.sort(resp)[-4] < resp[top3].min() - 1e-4
+    idx, _ = O.harris_keypoints(corner, None, 1.0)
+    assert 1 <= len(idx) <= 3 and set(idx.tolist()) <= set(top3.tolist())
+    # a plane has no corner response at all
+    plane, _ = F.generate_plane()
+    assert len(O.harris_keypoints(plane, None, 1.0)[0]) == 0
