@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
       }
       f = fn;
       for (int i = 0; i < 12; ++i) g12[i] = gn[i];
-      if (mx < 1e-12) break;
+      if (mx < 1e-9) break;
     }
     apply_state(x, T);
     // convergence test (gicp.hpp:526-541, 564-580)

@@ -805,7 +805,7 @@ static void build_quadform(const lo_functor* F, const float T0[16], lo_quadform*
 
 /* Gauss-Newton on the quadratic form; exposed shape shared with the device solver:
  * start at the Euler parameters of T (gicp.hpp:235-241), full steps with step halving when
- * the model cost does not decrease, stop when |dx|_inf < 1e-12, after max_inner steps or
+ * the model cost does not decrease, stop when |dx|_inf < 1e-9, after max_inner steps or
  * when no decrease is possible. */
 static int estimate_gn(lo_functor* F, int max_inner, float T[16]) {
   if (F->m < 4) return -1;
@@ -869,7 +869,7 @@ static int estimate_gn(lo_functor* F, int max_inner, float T[16]) {
     }
     theta_of_x(x, Th, dTh);
     f = quad_eval(&q, Th, g12);
-    if (mx < 1e-12) break;
+    if (mx < 1e-9) break;
   }
   lo_apply_state(x, T);
   return 0;
