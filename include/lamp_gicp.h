@@ -107,6 +107,8 @@ typedef struct lgicp_config {
                                  exhaustive 1-NN kernel (2, 4, 8); [1] its target splits;
                                  [2] 1 = use the exhaustive 1-NN kernel instead of the pruned
                                  one; [3] first-round radius of the pruned search in mm;
+                                 [4] -1 = TEASER++ clique search on the host instead of the device
+                                 (cross-checks), > 0 = diagnostics only: lookup cap in mm;
                                  [5] bit 0 = host round trip after every outer iteration, bit 1 = no
                                  limit-cycle exit from the outer loop; [6] 1 = no
                                  seeding of a lookup with the previous match, 2 = seeding but no

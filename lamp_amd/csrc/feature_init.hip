@@ -501,6 +501,10 @@ struct CliqueDev {
   }
   ~CliqueDev() { release(); }
 };
+CliqueDev& thread_clique_dev() {
+  thread_local CliqueDev dev;
+  return dev;
+}
 }  // namespace
 
 static bool clique_rotation_device(int device, const std::vector<double>& cs, const std::vector<double>& cd,
@@ -508,7 +512,7 @@ static bool clique_rotation_device(int device, const std::vector<double>& cs, co
   namespace tz = lgicp::teaser;
   const int m = (int)(cs.size() / 3);
   for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-  thread_local CliqueDev dev;
+  CliqueDev& dev = thread_clique_dev();
   if (!dev.bind(device)) return false;
   hipStream_t st = dev.st;
   bool ok = false;
@@ -622,13 +626,14 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
   tz::BitGraph& g = job->graph;
   g.n = n;
   g.words = (n + 63) / 64;
-  g.bits.resize((size_t)n * g.words);
+  const size_t n_words = (size_t)n * g.words;
   hipStream_t st = ctx->stream;
   Scratch dev;
   double* d_s = dev.alloc<double>(s.size());
   double* d_d = dev.alloc<double>(d.size());
-  unsigned long long* d_bits = dev.alloc<unsigned long long>(g.bits.size());
-  if (!d_s || !d_d || !d_bits) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  if (!d_s || !d_d || job->d_bits.reserve(n_words) != hipSuccess)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  unsigned long long* d_bits = job->d_bits.p;
   HIP_TRY(ctx, hipMemcpyAsync(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_d, d.data(), sizeof(double) * d.size(), hipMemcpyHostToDevice, st));
   const long long total = (long long)n * g.words;
@@ -636,8 +641,14 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
                      dim3(256), 0, st, d_s, d_d, n, g.words,
                      2.0 * prm.noise_bound * std::sqrt(prm.cbar2), d_bits);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(g.bits.data(), d_bits, sizeof(uint64_t) * g.bits.size(),
-                              hipMemcpyDeviceToHost, st));
+  // The graph stays on the device: core numbers and the clique search run there
+  // (teaser_graph.hip).  Only a graph too large for that path (or reserved[4] = -1: the host
+  // search, for cross-checks) is brought to the host.
+  g.bits.clear();
+  if (n > clique_device_max_vertices() || ctx->cfg.reserved[4] == -1) {
+    g.bits.resize(n_words);
+    HIP_TRY(ctx, hipMemcpyAsync(g.bits.data(), d_bits, sizeof(uint64_t) * n_words, hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return LGICP_OK;
 }
@@ -655,11 +666,20 @@ int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], f
   if (job.graph.n == 0) return LGICP_OK;
   const tz::Params prm;
   bool device_ok = true;
+  std::vector<int> clique;
+  if (job.graph.bits.empty()) {
+    CliqueDev& cd = thread_clique_dev();
+    if (!cd.bind(ctx->cfg.device) ||
+        !greedy_clique_device(ctx->cfg.device, cd.st, job.d_bits.p, job.graph.n, job.graph.words, &clique))
+      return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: clique search over %d matches failed on the "
+                  "device (%s)", job.graph.n, hipGetErrorString(hipGetLastError()));
+  } else {
+    // large graphs: a pair with ten thousand matches would otherwise keep one thread busy for
+    // hundreds of milliseconds after every other pair of the submit has finished
+    clique = tz::greedy_clique(job.graph, job.graph.n >= 2048 ? 8 : 1);
+  }
   const tz::Solution sol = tz::solve_on_clique(
-      job.src, job.dst,
-      // large graphs: a pair with ten thousand matches would otherwise keep one thread busy for
-      // hundreds of milliseconds after every other pair of the submit has finished
-      tz::greedy_clique(job.graph, job.graph.n >= 2048 ? 8 : 1), prm,
+      job.src, job.dst, std::move(clique), prm,
       [&](const std::vector<double>& cs, const std::vector<double>& cd, const tz::Params& p, double R[9]) {
         if (cs.size() / 3 < 128)
           tz::clique_rotation_host(cs, cd, p, R);

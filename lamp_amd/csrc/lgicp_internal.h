@@ -293,8 +293,20 @@ int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFea
 struct TeaserJob {
   int n_matches = 0;
   std::vector<double> src, dst;  // matched keypoints, [n_matches][3]
-  lgicp::teaser::BitGraph graph; // empty when there are too few matches to solve
+  // graph.n == 0 when there are too few matches to solve; graph.bits is filled only when the
+  // clique search runs on the host, otherwise the bit matrix lives in d_bits alone
+  lgicp::teaser::BitGraph graph;
+  DevBuf<unsigned long long> d_bits;  // [graph.n][graph.words], reused from pair to pair
+  TeaserJob() = default;
+  TeaserJob(const TeaserJob&) = delete;
+  TeaserJob& operator=(const TeaserJob&) = delete;
+  ~TeaserJob() { d_bits.release(); }
 };
+// teaser::greedy_clique on a bit matrix in device memory (teaser_graph.hip): core numbers and the
+// windows of starts run on `st`; false when the device refuses
+bool greedy_clique_device(int device, hipStream_t st, const unsigned long long* d_bits, int n, int words,
+                          std::vector<int>* clique);
+int clique_device_max_vertices();
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                           TeaserJob* job);
 int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], float T_out[16],

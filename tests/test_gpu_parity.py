@@ -560,6 +560,29 @@ def test_teaser_large_clique_matches_oracle():
         c.close()
 
 
+def test_teaser_device_clique_search_equals_host_search():
+    """Core numbers and the greedy clique heuristic on the device (teaser_graph.hip) against the
+    same heuristic on the host (reserved[4] = -1): same clique size, same transformation, on match
+    sets from a few hundred to several thousand."""
+    from lamp_amd import capi
+    host_cfg = [0] * 8
+    host_cfg[4] = -1
+    for n, seed, radius in [(3000, 51, 0.5), (6000, 52, 0.3), (12000, 47, 0.15), (9000, 53, 0.2)]:
+        src, sn, tgt, tn, _ = F.make_pair(n, seed, rot_deg=4.0, trans=0.4)
+        out = []
+        for res in (None, host_cfg):
+            kw = {} if res is None else {"reserved": (capi.C.c_int * 8)(*res)}
+            c = capi.Context(harris_radius=radius, **kw)
+            try:
+                out.append(c.teaser_initial_alignment(src, sn, tgt, tn, None))
+            finally:
+                c.close()
+        (T_d, used_d, nm_d, nc_d), (T_h, used_h, nm_h, nc_h) = out
+        assert nm_d == nm_h and nm_d > 10
+        assert nc_d == nc_h and used_d == used_h, (n, nm_d, nc_d, nc_h)
+        assert np.array_equal(T_d, T_h)
+
+
 def test_submit_teaser_init_matches_oracle():
     from lamp_amd import capi
     radius = 0.3
