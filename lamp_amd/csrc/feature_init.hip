@@ -10,7 +10,10 @@
 // host then replays the "first strictly lower" selection.  The descriptor k-NN table (33-D,
 // squared L2, k = 5) is one more small exhaustive kernel.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <climits>
+#include <thread>
 
 #include "lgicp_internal.h"
 #include "sac_ia.h"
@@ -215,32 +218,56 @@ __global__ __launch_bounds__(SS_THREADS) void sac_score_kernel(const float* __re
   }
 }
 
+// The matches as TEASER++ sees them: match i * k + q pairs source keypoint i with its q-th nearest
+// target keypoint in descriptor space; coordinates widened to double.
+__global__ __launch_bounds__(256) void match_points_kernel(const int* __restrict__ nn, const float* __restrict__ src_xyz,
+                                                           const float* __restrict__ tgt_xyz, int n_src, int k,
+                                                           double* __restrict__ s, double* __restrict__ d) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= n_src * k) return;
+  const int i = m / k, t = nn[m];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    s[3 * m + c] = (double)src_xyz[3 * i + c];
+    d[3 * m + c] = (double)tgt_xyz[3 * t + c];
+  }
+}
+
 // Scale-consistency graph of n matches (TEASER++'s inlier graph when no scale is estimated):
-// bit j of row i is set when | |s_j - s_i| - |d_j - d_i| | <= beta.  One lane per 64-bit word.
+// bit j of row i is set when | |s_j - s_i| - |d_j - d_i| | <= beta.  A wave owns one 64-bit word
+// column (its 64 matches j sit in registers, one per lane) and 64 rows: the row's match is read
+// with wave-uniform addresses, all lanes test it against their own, and the ballot of the 64 tests
+// is the word of that row; lane r keeps the word of row r, so the 64 words leave in one store.
 __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __restrict__ src,
                                                                 const double* __restrict__ dst,
                                                                 int n, int words, double beta,
                                                                 unsigned long long* __restrict__ bits) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long long)n * words) return;
-  const int i = (int)(gid / words), w = (int)(gid % words);
-  const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
-  const double dx = dst[3 * i], dy = dst[3 * i + 1], dz = dst[3 * i + 2];
-  unsigned long long m = 0;
-  for (int b = 0; b < 64; ++b) {
-    const int j = w * 64 + b;
-    if (j >= n) break;
-    if (j == i) continue;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = blockIdx.x;
+  const int i0 = (blockIdx.y * 4 + wv) * 64;
+  if (i0 >= n) return;  // wave-uniform
+  const int j = w * 64 + lane;
+  const bool jv = j < n;
+  const int jj = jv ? j : 0;
+  const double sjx = src[3 * jj], sjy = src[3 * jj + 1], sjz = src[3 * jj + 2];
+  const double djx = dst[3 * jj], djy = dst[3 * jj + 1], djz = dst[3 * jj + 2];
+  const int rows = min(64, n - i0);
+  unsigned long long mine = 0;
+  for (int r = 0; r < rows; ++r) {
+    const int i = i0 + r;
+    const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+    const double dx = dst[3 * i], dy = dst[3 * i + 1], dz = dst[3 * i + 2];
     double e, a = 0, c = 0;
-    e = src[3 * j] - sx, a += e * e;
-    e = src[3 * j + 1] - sy, a += e * e;
-    e = src[3 * j + 2] - sz, a += e * e;
-    e = dst[3 * j] - dx, c += e * e;
-    e = dst[3 * j + 1] - dy, c += e * e;
-    e = dst[3 * j + 2] - dz, c += e * e;
-    if (fabs(sqrt(a) - sqrt(c)) <= beta) m |= 1ull << b;
+    e = sjx - sx, a += e * e;
+    e = sjy - sy, a += e * e;
+    e = sjz - sz, a += e * e;
+    e = djx - dx, c += e * e;
+    e = djy - dy, c += e * e;
+    e = djz - dz, c += e * e;
+    const unsigned long long m = __ballot(jv && j != i && fabs(sqrt(a) - sqrt(c)) <= beta);
+    if (lane == r) mine = m;
   }
-  bits[gid] = m;
+  if (lane < rows) bits[(size_t)(i0 + lane) * words + w] = mine;
 }
 
 
@@ -259,16 +286,35 @@ struct GncStep {
   int init;                // old weights are 1 (nothing stored yet)
   int update;              // write the new weights and use them for the correlation
 };
+// One clique of a group: every launch carries an iteration of all cliques still iterating
+// (blockIdx.z), each with its own rotation and thresholds.
+struct GncJobDev {
+  GncStep k;
+  int m;             // clique members
+  int pt_off;        // its first point in the shared point arrays
+  int gx;            // workgroups per row = ceil(m / GNC_THREADS)
+  int part_off;      // its first row of partial values
+  long long w_off;   // its first weight
+  long long out_off; // its row of folded values
+};
 constexpr int GNC_THREADS = 256;
 constexpr int GNC_VALUES = 11;  // H (9), cost, max residual
 
-__global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __restrict__ cs,
-                                                               const double* __restrict__ cd,
-                                                               int m, GncStep k,
-                                                               double* __restrict__ w,
-                                                               double* __restrict__ partial) {
+__global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __restrict__ cs_all,
+                                                               const double* __restrict__ cd_all,
+                                                               const GncJobDev* __restrict__ jobs,
+                                                               double* __restrict__ w_all,
+                                                               double* __restrict__ partial_all) {
   __shared__ double sh[GNC_THREADS / 64][GNC_VALUES];
-  const int i = blockIdx.y, j = blockIdx.x * GNC_THREADS + threadIdx.x;
+  const GncJobDev* J = jobs + blockIdx.z;
+  const int m = J->m, gx = J->gx;
+  const int i = blockIdx.y;
+  if (i >= m || (int)blockIdx.x >= gx) return;  // the grid spans the largest clique of the group
+  const GncStep& k = J->k;
+  const double* cs = cs_all + 3 * (size_t)J->pt_off;
+  const double* cd = cd_all + 3 * (size_t)J->pt_off;
+  double* w = w_all + J->w_off;
+  const int j = blockIdx.x * GNC_THREADS + threadIdx.x;
   double v[GNC_VALUES];
 #pragma unroll
   for (int q = 0; q < GNC_VALUES; ++q) v[q] = 0.0;
@@ -311,15 +357,19 @@ __global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __r
     const int q = threadIdx.x;
     double a = sh[0][q];
     for (int wv = 1; wv < GNC_THREADS / 64; ++wv) a = q == 10 ? fmax(a, sh[wv][q]) : a + sh[wv][q];
-    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * GNC_VALUES + q] = a;
+    partial_all[((size_t)J->part_off + (size_t)blockIdx.y * gx + blockIdx.x) * GNC_VALUES + q] = a;
   }
 }
 
-// out[q] = fold of partial[0..n)[q]: lane t adds rows t, t + 256, ... in order, then the 256
-// lane sums are added in lane order
-__global__ __launch_bounds__(GNC_THREADS) void gnc_fold_kernel(const double* __restrict__ partial,
-                                                               int n, double* __restrict__ out) {
+// out[job][q] = fold of the job's partial rows: lane t adds rows t, t + 256, ... in order, then
+// the 256 lane sums are added in lane order.  One workgroup per clique.
+__global__ __launch_bounds__(GNC_THREADS) void gnc_fold_kernel(const double* __restrict__ partial_all,
+                                                               const GncJobDev* __restrict__ jobs,
+                                                               double* __restrict__ out_all) {
   __shared__ double sh[GNC_THREADS][GNC_VALUES];
+  const GncJobDev* J = jobs + blockIdx.x;
+  const double* partial = partial_all + (size_t)J->part_off * GNC_VALUES;
+  const int n = J->gx * J->m;
   double v[GNC_VALUES];
 #pragma unroll
   for (int q = 0; q < GNC_VALUES; ++q) v[q] = 0.0;
@@ -336,7 +386,7 @@ __global__ __launch_bounds__(GNC_THREADS) void gnc_fold_kernel(const double* __r
     const int q = threadIdx.x;
     double a = sh[0][q];
     for (int t = 1; t < GNC_THREADS; ++t) a = q == 10 ? fmax(a, sh[t][q]) : a + sh[t][q];
-    out[q] = a;
+    out_all[J->out_off * GNC_VALUES + q] = a;
   }
 }
 
@@ -360,8 +410,13 @@ struct Scratch {
 };
 }  // namespace
 
+static MatcherDev& matcher_of(lgicp_ctx* ctx) {
+  if (!ctx->matcher) ctx->matcher = std::make_shared<MatcherDev>();
+  return *ctx->matcher;
+}
+
 // descriptor k-NN table [n_src][k] (device pointers; partial lists live in `d`)
-static int launch_feature_knn(lgicp_ctx* ctx, Scratch& d, const float* d_sf, int n_src,
+static int launch_feature_knn(lgicp_ctx* ctx, MatcherDev& d, const float* d_sf, int n_src,
                               const float* d_tf, int n_tgt, int k, int* d_nn, hipStream_t st) {
   const int src_blocks = (n_src + 127) / 128;
   // enough target ranges for ~4 workgroups per CU, each at least four tiles long
@@ -370,9 +425,11 @@ static int launch_feature_knn(lgicp_ctx* ctx, Scratch& d, const float* d_sf, int
   int per_split = (n_tgt + n_splits - 1) / n_splits;
   per_split = ((per_split + lgicp::FK_TILE - 1) / lgicp::FK_TILE) * lgicp::FK_TILE;
   n_splits = (n_tgt + per_split - 1) / per_split;
-  float* d_pd = d.alloc<float>((size_t)n_splits * n_src * 8);
-  int* d_pi = d.alloc<int>((size_t)n_splits * n_src * 8);
-  if (!d_pd || !d_pi) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  if (d.part_d.reserve((size_t)n_splits * n_src * 8) != hipSuccess ||
+      d.part_i.reserve((size_t)n_splits * n_src * 8) != hipSuccess)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  float* d_pd = d.part_d.p;
+  int* d_pi = d.part_i.p;
   hipLaunchKernelGGL(lgicp::feature_knn_kernel, dim3(src_blocks, n_splits), dim3(128), 0, st, d_sf,
                      n_src, d_tf, n_tgt, per_split, k, d_pd, d_pi);
   hipLaunchKernelGGL(lgicp::feature_knn_merge_kernel, dim3((n_src + 127) / 128), dim3(128), 0, st,
@@ -392,21 +449,21 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
   const int k = std::min(5, n_tgt);  // setCorrespondenceRandomness(5), IcpLoopComputation.cc:697
   hipStream_t st = ctx->stream;
   Scratch d;
-  float* d_sf = d.alloc<float>(src.feat.size());
-  float* d_tf = d.alloc<float>(tgt.feat.size());
-  int* d_nn = d.alloc<int>((size_t)n_src * k);
+  MatcherDev& md = matcher_of(ctx);
+  const float* d_sf = src.d_feat;  // descriptors stay on the device with the cloud's features
+  const float* d_tf = tgt.d_feat;
   float4* d_sk = d.alloc<float4>(n_src);
   float4* d_tk = d.alloc<float4>(n_tgt);
-  if (!d_sf || !d_tf || !d_nn || !d_sk || !d_tk) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  if (!d_sf || !d_tf || md.nn.reserve((size_t)n_src * k) != hipSuccess || !d_sk || !d_tk)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  int* d_nn = md.nn.p;
   std::vector<float4> hs(n_src), ht(n_tgt);
   for (int i = 0; i < n_src; ++i) hs[i] = make_float4(src.xyz[3 * i], src.xyz[3 * i + 1], src.xyz[3 * i + 2], 1.f);
   for (int i = 0; i < n_tgt; ++i) ht[i] = make_float4(tgt.xyz[3 * i], tgt.xyz[3 * i + 1], tgt.xyz[3 * i + 2], 1.f);
-  HIP_TRY(ctx, hipMemcpyAsync(d_sf, src.feat.data(), sizeof(float) * src.feat.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(d_tf, tgt.feat.data(), sizeof(float) * tgt.feat.size(), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_sk, hs.data(), sizeof(float4) * n_src, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_tk, ht.data(), sizeof(float4) * n_tgt, hipMemcpyHostToDevice, st));
   {
-    const int rc = launch_feature_knn(ctx, d, d_sf, n_src, d_tf, n_tgt, k, d_nn, st);
+    const int rc = launch_feature_knn(ctx, md, d_sf, n_src, d_tf, n_tgt, k, d_nn, st);
     if (rc != LGICP_OK) return rc;
   }
   std::vector<int> nn((size_t)n_src * k);
@@ -443,148 +500,224 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
   return LGICP_OK;
 }
 
-// descriptor k-NN table [n_src][k] on the device
-static int feature_knn_table(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                             int k, std::vector<int>* nn) {
-  const int n_src = (int)src.idx.size(), n_tgt = (int)tgt.idx.size();
-  hipStream_t st = ctx->stream;
-  Scratch d;
-  float* d_sf = d.alloc<float>(src.feat.size());
-  float* d_tf = d.alloc<float>(tgt.feat.size());
-  int* d_nn = d.alloc<int>((size_t)n_src * k);
-  if (!d_sf || !d_tf || !d_nn) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
-  HIP_TRY(ctx, hipMemcpyAsync(d_sf, src.feat.data(), sizeof(float) * src.feat.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(d_tf, tgt.feat.data(), sizeof(float) * tgt.feat.size(), hipMemcpyHostToDevice, st));
-  {
-    const int rc = launch_feature_knn(ctx, d, d_sf, n_src, d_tf, n_tgt, k, d_nn, st);
-    if (rc != LGICP_OK) return rc;
-  }
-  nn->resize((size_t)n_src * k);
-  HIP_TRY(ctx, hipMemcpyAsync(nn->data(), d_nn, sizeof(int) * nn->size(), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  return LGICP_OK;
-}
-
-// teaser::clique_rotation_host with the sums over the pairwise differences on the device.
-// Runs on a stream of the calling thread: several pairs are solved at once from different host
-// threads.  Returns false when the device refuses (the caller reports it).
+// teaser::clique_rotation_host for a group of cliques, with the sums over the pairwise differences
+// on the device: all cliques iterate together, one launch pair (step + fold) and one round trip of
+// 11 sums per clique and iteration; the 3x3 SVDs in between stay on the host.
 namespace {
-// Stream and buffers of the clique rotation search, one set per host thread (several pairs are
-// solved at once from different threads) and reused from clique to clique; released when the
-// thread ends.  Bound to the device that was current when they were made.
-struct CliqueDev {
+struct PinBuf {  // grow-only pinned host array
+  char* p = nullptr;
+  size_t cap = 0;
+  bool reserve(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
+      p = nullptr;
+      return false;
+    }
+    cap = want;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+  }
+};
+// Buffers of the rotation search, one set per host thread and reused from group to group;
+// released when the thread ends.  Bound to the device that was current when they were made.
+struct GncGroupDev {
   int device = -1;
-  hipStream_t st = nullptr;
   DevBuf<double> cs, cd, w, partial, out;
+  DevBuf<lgicp::GncJobDev> table;
+  PinBuf h_up, h_down;
   void release() {
     if (device >= 0) {
       int cur = -1;
       (void)hipGetDevice(&cur);
       if (cur != device) (void)hipSetDevice(device);
-      cs.release(), cd.release(), w.release(), partial.release(), out.release();
-      if (st) (void)hipStreamDestroy(st);
+      cs.release(), cd.release(), w.release(), partial.release(), out.release(), table.release();
+      h_up.release(), h_down.release();
       if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
-    st = nullptr;
     device = -1;
   }
-  bool bind(int dev) {
-    if (device == dev && st) return true;
-    release();
-    if (hipSetDevice(dev) != hipSuccess) return false;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-      st = nullptr;
-      return false;
-    }
-    device = dev;
-    return true;
-  }
-  ~CliqueDev() { release(); }
+  ~GncGroupDev() { release(); }
 };
-CliqueDev& thread_clique_dev() {
-  thread_local CliqueDev dev;
-  return dev;
+
+struct RotJob {
+  const std::vector<double>* cs;
+  const std::vector<double>* cd;
+  double* R;  // [9], out
+};
+
+template <class F>
+void parallel_for(int n, F f) {
+  const int nt = std::min(n, (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+  if (nt <= 1) {
+    for (int i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::atomic<int> next{0};
+  auto run = [&] {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) return;
+      f(i);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(run);
+  run();
+  for (std::thread& t : pool) t.join();
 }
 }  // namespace
 
-static bool clique_rotation_device(int device, const std::vector<double>& cs, const std::vector<double>& cd,
-                                   const lgicp::teaser::Params& p, double R[9]) {
+static bool clique_rotation_group(int device, hipStream_t st, RotJob* jobs, int count,
+                                  const lgicp::teaser::Params& p) {
   namespace tz = lgicp::teaser;
-  const int m = (int)(cs.size() / 3);
-  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-  CliqueDev& dev = thread_clique_dev();
-  if (!dev.bind(device)) return false;
-  hipStream_t st = dev.st;
-  bool ok = false;
-  {
-    const dim3 grid((m + lgicp::GNC_THREADS - 1) / lgicp::GNC_THREADS, m);
-    const int n_partial = (int)(grid.x * grid.y);
-    if (dev.cs.reserve(cs.size()) != hipSuccess || dev.cd.reserve(cd.size()) != hipSuccess ||
-        dev.w.reserve((size_t)m * m) != hipSuccess ||
-        dev.partial.reserve((size_t)n_partial * lgicp::GNC_VALUES) != hipSuccess ||
-        dev.out.reserve(lgicp::GNC_VALUES) != hipSuccess)
-      return false;
-    double* d_cs = dev.cs.p;
-    double* d_cd = dev.cd.p;
-    double* d_w = dev.w.p;
-    double* d_partial = dev.partial.p;
-    double* d_out = dev.out.p;
-    double out[lgicp::GNC_VALUES];
-    auto step = [&](lgicp::GncStep k) -> bool {
-      hipLaunchKernelGGL(lgicp::gnc_step_kernel, grid, dim3(lgicp::GNC_THREADS), 0, st, d_cs, d_cd, m,
-                         k, d_w, d_partial);
-      hipLaunchKernelGGL(lgicp::gnc_fold_kernel, dim3(1), dim3(lgicp::GNC_THREADS), 0, st, d_partial,
-                         n_partial, d_out);
-      return hipGetLastError() == hipSuccess &&
-             hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, st) == hipSuccess &&
-             hipStreamSynchronize(st) == hipSuccess;
+  using lgicp::GncJobDev;
+  using lgicp::GncStep;
+  if (count == 0) return true;
+  thread_local GncGroupDev dev;
+  if (dev.device != device) {
+    dev.release();
+    if (hipSetDevice(device) != hipSuccess) return false;
+    dev.device = device;
+  }
+  double nb2 = p.noise_bound * p.noise_bound;
+  if (nb2 < 1e-16) nb2 = 1e-2;
+  // the weights are m x m doubles per clique: groups of cliques whose weights fit 4 GiB
+  int first = 0;
+  while (first < count) {
+    int last = first;
+    size_t n_w = 0, n_pt = 0, n_part = 0;
+    int max_m = 0, max_gx = 0;
+    struct State {
+      GncJobDev d;
+      int stage = 0, it = 0;  // 0, 1: the two unweighted steps; 2: the GNC loop
+      double mu = 0, prev_cost = INFINITY;
+      bool done = false;
     };
-    if (hipMemcpyAsync(d_cs, cs.data(), sizeof(double) * cs.size(), hipMemcpyHostToDevice, st) == hipSuccess &&
-        hipMemcpyAsync(d_cd, cd.data(), sizeof(double) * cd.size(), hipMemcpyHostToDevice, st) == hipSuccess) {
-      ok = true;
-      double nb2 = p.noise_bound * p.noise_bound;
-      if (nb2 < 1e-16) nb2 = 1e-2;
-      lgicp::GncStep k{};
-      for (int i = 0; i < 9; ++i) k.R[i] = R[i];
-      k.init = 1;
-      // iteration 0 needs the largest residual under the unweighted rotation before it can
-      // set its weights: correlation of unit weights, then the residuals, then the update
-      ok = ok && step(k);
-      if (ok) {
-        tz::rotation_from_correlation(out, R);
-        for (int i = 0; i < 9; ++i) k.R[i] = R[i];
-        ok = step(k);
+    std::vector<State> S;
+    while (last < count) {
+      const int m = (int)(jobs[last].cs->size() / 3);
+      const size_t w_m = (size_t)m * m;
+      if (last > first && (n_w + w_m) * sizeof(double) > (4ull << 30)) break;
+      State s;
+      s.d.m = m;
+      s.d.pt_off = (int)n_pt;
+      s.d.gx = (m + lgicp::GNC_THREADS - 1) / lgicp::GNC_THREADS;
+      s.d.part_off = (int)n_part;
+      s.d.w_off = (long long)n_w;
+      s.d.out_off = (long long)(last - first);
+      std::memset(&s.d.k, 0, sizeof(s.d.k));
+      for (int i = 0; i < 9; ++i) s.d.k.R[i] = jobs[last].R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+      s.d.k.init = 1;
+      S.push_back(s);
+      n_w += w_m, n_pt += (size_t)m, n_part += (size_t)s.d.gx * m;
+      max_m = std::max(max_m, m), max_gx = std::max(max_gx, s.d.gx);
+      ++last;
+    }
+    const int A = last - first;
+    if (n_part > (size_t)INT_MAX || n_pt > (size_t)INT_MAX) return false;
+    if (dev.cs.reserve(3 * n_pt) != hipSuccess || dev.cd.reserve(3 * n_pt) != hipSuccess ||
+        dev.w.reserve(n_w) != hipSuccess || dev.partial.reserve(n_part * lgicp::GNC_VALUES) != hipSuccess ||
+        dev.out.reserve((size_t)A * lgicp::GNC_VALUES) != hipSuccess || dev.table.reserve((size_t)A) != hipSuccess ||
+        !dev.h_up.reserve(std::max(sizeof(double) * 6 * n_pt, sizeof(GncJobDev) * (size_t)A)) ||
+        !dev.h_down.reserve(sizeof(double) * (size_t)A * lgicp::GNC_VALUES))
+      return false;
+    {
+      double* h = reinterpret_cast<double*>(dev.h_up.p);
+      for (int a = 0; a < A; ++a) {
+        const RotJob& j = jobs[first + a];
+        std::memcpy(h + 3 * (size_t)S[a].d.pt_off, j.cs->data(), sizeof(double) * j.cs->size());
+        std::memcpy(h + 3 * n_pt + 3 * (size_t)S[a].d.pt_off, j.cd->data(), sizeof(double) * j.cd->size());
       }
-      double mu = ok ? 1.0 / (2.0 * out[10] / nb2 - 1.0) : 0.0;
-      double prev_cost = INFINITY;
-      for (int it = 0; ok && mu > 0 && it < p.rotation_max_iterations; ++it) {
-        if (it > 0) {
+      if (hipMemcpyAsync(dev.cs.p, h, sizeof(double) * 3 * n_pt, hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(dev.cd.p, h + 3 * n_pt, sizeof(double) * 3 * n_pt, hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)  // h_up carries the tables from here on
+        return false;
+    }
+    std::vector<int> active;
+    for (;;) {
+      active.clear();
+      for (int a = 0; a < A; ++a)
+        if (!S[a].done) active.push_back(a);
+      if (active.empty()) break;
+      GncJobDev* h_tab = reinterpret_cast<GncJobDev*>(dev.h_up.p);
+      int gm = 0, gg = 0;
+      for (size_t z = 0; z < active.size(); ++z) {
+        h_tab[z] = S[active[z]].d;
+        h_tab[z].out_off = (long long)z;
+        gm = std::max(gm, h_tab[z].m), gg = std::max(gg, h_tab[z].gx);
+      }
+      const double* h_out = reinterpret_cast<const double*>(dev.h_down.p);
+      if (hipMemcpyAsync(dev.table.p, h_tab, sizeof(GncJobDev) * active.size(), hipMemcpyHostToDevice, st) != hipSuccess)
+        return false;
+      hipLaunchKernelGGL(lgicp::gnc_step_kernel, dim3(gg, gm, (unsigned)active.size()), dim3(lgicp::GNC_THREADS), 0,
+                         st, dev.cs.p, dev.cd.p, dev.table.p, dev.w.p, dev.partial.p);
+      hipLaunchKernelGGL(lgicp::gnc_fold_kernel, dim3((unsigned)active.size()), dim3(lgicp::GNC_THREADS), 0, st,
+                         dev.partial.p, dev.table.p, dev.out.p);
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(dev.h_down.p, dev.out.p, sizeof(double) * active.size() * lgicp::GNC_VALUES,
+                         hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        return false;
+      for (size_t z = 0; z < active.size(); ++z) {
+        State& s = S[active[z]];
+        const double* out = h_out + z * lgicp::GNC_VALUES;
+        double* R = jobs[first + active[z]].R;
+        GncStep& k = s.d.k;
+        auto next_loop_step = [&] {  // thresholds of GNC iteration s.it
+          k.update = 1;
+          k.th1 = (s.mu + 1) / s.mu * nb2;
+          k.th2 = s.mu / (s.mu + 1) * nb2;
+          k.c = nb2 * s.mu * (s.mu + 1);
+          k.mu = s.mu;
+        };
+        if (s.stage == 0) {
+          // iteration 0 needs the largest residual under the unweighted rotation before it can
+          // set its weights: correlation of unit weights, then the residuals, then the update
           tz::rotation_from_correlation(out, R);
           for (int i = 0; i < 9; ++i) k.R[i] = R[i];
-          k.init = 0;
+          s.stage = 1;
+        } else if (s.stage == 1) {
+          s.mu = 1.0 / (2.0 * out[10] / nb2 - 1.0);
+          s.prev_cost = INFINITY;
+          s.it = 0;
+          if (!(s.mu > 0) || p.rotation_max_iterations <= 0) {
+            s.done = true;
+          } else {
+            s.stage = 2;
+            next_loop_step();
+          }
+        } else {
+          const double cost = out[9];
+          const double cost_diff = std::fabs(cost - s.prev_cost);
+          s.mu *= p.rotation_gnc_factor;
+          s.prev_cost = cost;
+          ++s.it;
+          if (cost_diff < p.rotation_cost_threshold || !(s.mu > 0) || s.it >= p.rotation_max_iterations) {
+            s.done = true;
+          } else {
+            tz::rotation_from_correlation(out, R);
+            for (int i = 0; i < 9; ++i) k.R[i] = R[i];
+            k.init = 0;
+            next_loop_step();
+          }
         }
-        k.update = 1;
-        k.th1 = (mu + 1) / mu * nb2;
-        k.th2 = mu / (mu + 1) * nb2;
-        k.c = nb2 * mu * (mu + 1);
-        k.mu = mu;
-        ok = step(k);
-        const double cost = out[9];
-        const double cost_diff = std::fabs(cost - prev_cost);
-        mu *= p.rotation_gnc_factor;
-        prev_cost = cost;
-        if (cost_diff < p.rotation_cost_threshold) break;
       }
     }
+    first = last;
   }
-  // a failed call may have left work queued on the stream: nothing may still read the buffers
-  // when the next clique overwrites them
-  if (!ok) (void)hipStreamSynchronize(st);
-  return ok;
+  return true;
 }
 
 // GetTeaserInitialAlignment from the keypoints on (IcpLoopComputation.cc:990-1081), first half:
-// descriptor matches and their scale-consistency graph, both built on the device.
+// descriptor matches and their scale-consistency graph, built on the device from the descriptors
+// and keypoints the clouds' features keep there.  Everything is enqueued on the context's stream
+// and the call returns; the matched keypoints land in the job's pinned buffer.
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                           TeaserJob* job) {
   namespace tz = lgicp::teaser;
@@ -595,9 +728,6 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
   const int n_src = (int)src.idx.size(), n_tgt = (int)tgt.idx.size();
   if (n_src == 0 || n_tgt == 0) return LGICP_OK;
   const int k = std::min(5, n_tgt);  // calculateKCorrespondences(..., 5), IcpLoopComputation.cc:997
-  std::vector<int> nn;
-  int rc = feature_knn_table(ctx, src, tgt, k, &nn);
-  if (rc != LGICP_OK) return rc;
   const int n = n_src * k;
   job->n_matches = n;
   if (n <= 10) return LGICP_OK;  // IcpLoopComputation.cc:1002
@@ -612,99 +742,146 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
                    "is sized for; the pair keeps its guess\n", n, kMaxMatches);
     return LGICP_OK;
   }
-  std::vector<double>& s = job->src;
-  std::vector<double>& d = job->dst;
-  s.resize((size_t)3 * n);
-  d.resize((size_t)3 * n);
-  for (int i = 0; i < n_src; ++i)
-    for (int q = 0; q < k; ++q)
-      for (int c = 0; c < 3; ++c) {
-        s[3 * ((size_t)i * k + q) + c] = (double)src.xyz[3 * i + c];
-        d[3 * ((size_t)i * k + q) + c] = (double)tgt.xyz[3 * nn[(size_t)i * k + q] + c];
-      }
+  if (!src.d_feat || !tgt.d_feat) return fail(ctx, LGICP_E_INVALID, "cloud features without device copies");
+  hipStream_t st = ctx->stream;
+  MatcherDev& md = matcher_of(ctx);
   const tz::Params prm;
   tz::BitGraph& g = job->graph;
   g.n = n;
   g.words = (n + 63) / 64;
   const size_t n_words = (size_t)n * g.words;
-  hipStream_t st = ctx->stream;
-  Scratch dev;
-  double* d_s = dev.alloc<double>(s.size());
-  double* d_d = dev.alloc<double>(d.size());
-  if (!d_s || !d_d || job->d_bits.reserve(n_words) != hipSuccess)
+  const size_t sd_bytes = sizeof(double) * 6 * (size_t)n;
+  if (job->h_sd_cap < sd_bytes) {
+    if (job->h_sd) (void)hipHostFree(job->h_sd);
+    job->h_sd = nullptr, job->h_sd_cap = 0;
+    const size_t want = sd_bytes + sd_bytes / 4;
+    if (hipHostMalloc((void**)&job->h_sd, want, hipHostMallocDefault) != hipSuccess) {
+      job->h_sd = nullptr;
+      return fail(ctx, LGICP_E_NOMEM, "pinned allocation failed");
+    }
+    job->h_sd_cap = want;
+  }
+  if (md.nn.reserve((size_t)n) != hipSuccess || job->d_sd.reserve(6 * (size_t)n) != hipSuccess ||
+      job->d_bits.reserve(n_words) != hipSuccess)
     return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
-  unsigned long long* d_bits = job->d_bits.p;
-  HIP_TRY(ctx, hipMemcpyAsync(d_s, s.data(), sizeof(double) * s.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipMemcpyAsync(d_d, d.data(), sizeof(double) * d.size(), hipMemcpyHostToDevice, st));
-  const long long total = (long long)n * g.words;
-  hipLaunchKernelGGL(lgicp::consistency_graph_kernel, dim3((unsigned)((total + 255) / 256)),
-                     dim3(256), 0, st, d_s, d_d, n, g.words,
-                     2.0 * prm.noise_bound * std::sqrt(prm.cbar2), d_bits);
+  {
+    const int rc = launch_feature_knn(ctx, md, src.d_feat, n_src, tgt.d_feat, n_tgt, k, md.nn.p, st);
+    if (rc != LGICP_OK) return rc;
+  }
+  double* d_s = job->d_sd.p;
+  double* d_d = job->d_sd.p + 3 * (size_t)n;
+  hipLaunchKernelGGL(lgicp::match_points_kernel, dim3((n + 255) / 256), dim3(256), 0, st, md.nn.p, src.d_kxyz,
+                     tgt.d_kxyz, n_src, k, d_s, d_d);
+  hipLaunchKernelGGL(lgicp::consistency_graph_kernel, dim3(g.words, (n + 255) / 256), dim3(256), 0, st, d_s,
+                     d_d, n, g.words, 2.0 * prm.noise_bound * std::sqrt(prm.cbar2), job->d_bits.p);
   HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(job->h_sd, job->d_sd.p, sd_bytes, hipMemcpyDeviceToHost, st));
   // The graph stays on the device: core numbers and the clique search run there
   // (teaser_graph.hip).  Only a graph too large for that path (or reserved[4] = -1: the host
   // search, for cross-checks) is brought to the host.
   g.bits.clear();
   if (n > clique_device_max_vertices() || ctx->cfg.reserved[4] == -1) {
     g.bits.resize(n_words);
-    HIP_TRY(ctx, hipMemcpyAsync(g.bits.data(), d_bits, sizeof(uint64_t) * n_words, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(g.bits.data(), job->d_bits.p, sizeof(uint64_t) * n_words, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
   }
-  HIP_TRY(ctx, hipStreamSynchronize(st));
   return LGICP_OK;
 }
 
-// Second half (safe to run for several pairs at once from different threads): clique, rotation,
-// translation and the acceptance test.  Graph work and 3x3 algebra stay on the host; the sums
-// over the clique's pairwise differences go to the device once the clique is large enough to
-// pay for the launches.  T_out is the guess unless the TEASER++ transform scores at least as
-// well over the matches.
-int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], float T_out[16],
-                  int* used, int* n_clique) {
+// after the stream has been synchronised: the matched keypoints as the host half wants them
+void teaser_prepare_collect(TeaserJob* job) {
+  const size_t n = (size_t)job->graph.n;
+  if (n == 0) return;
+  job->src.assign(job->h_sd, job->h_sd + 3 * n);
+  job->dst.assign(job->h_sd + 3 * n, job->h_sd + 6 * n);
+}
+
+// Second half, for a group of pairs at once: clique, rotation, translation and the acceptance
+// test.  The clique search (teaser_graph.hip) and the sums over the cliques' pairwise differences
+// advance all pairs of the group together on the device; 3x3 algebra, the translation vote and the
+// error metrics are host work spread over threads.  T_out[i] is the guess unless the TEASER++
+// transform scores at least as well over the matches.
+int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
+                        float (*T_out)[16], int* used, int* n_clique) {
   namespace tz = lgicp::teaser;
-  std::memcpy(T_out, guess, sizeof(float) * 16);
-  *used = *n_clique = 0;
-  if (job.graph.n == 0) return LGICP_OK;
+  for (int i = 0; i < count; ++i) {
+    std::memcpy(T_out[i], guesses[i], sizeof(float) * 16);
+    used[i] = n_clique[i] = 0;
+  }
   const tz::Params prm;
-  bool device_ok = true;
-  std::vector<int> clique;
-  if (job.graph.bits.empty()) {
-    CliqueDev& cd = thread_clique_dev();
-    if (!cd.bind(ctx->cfg.device) ||
-        !greedy_clique_device(ctx->cfg.device, cd.st, job.d_bits.p, job.graph.n, job.graph.words, &clique))
-      return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: clique search over %d matches failed on the "
-                  "device (%s)", job.graph.n, hipGetErrorString(hipGetLastError()));
-  } else {
-    // large graphs: a pair with ten thousand matches would otherwise keep one thread busy for
-    // hundreds of milliseconds after every other pair of the submit has finished
-    clique = tz::greedy_clique(job.graph, job.graph.n >= 2048 ? 8 : 1);
-  }
-  const tz::Solution sol = tz::solve_on_clique(
-      job.src, job.dst, std::move(clique), prm,
-      [&](const std::vector<double>& cs, const std::vector<double>& cd, const tz::Params& p, double R[9]) {
-        if (cs.size() / 3 < 128)
-          tz::clique_rotation_host(cs, cd, p, R);
-        else
-          device_ok = clique_rotation_device(ctx->cfg.device, cs, cd, p, R);
-      });
-  if (!device_ok)
-    return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: rotation search over a clique of %d matches "
-                "failed on the device (%s)", (int)sol.clique.size(), hipGetErrorString(hipGetLastError()));
-  *n_clique = (int)sol.clique.size();
-  double Ro[9], to[3];
-  for (int a = 0; a < 3; ++a) {
-    for (int b = 0; b < 3; ++b) Ro[a * 3 + b] = (double)guess[a * 4 + b];
-    to[a] = (double)guess[a * 4 + 3];
-  }
-  const double e_teaser = tz::error_metric(job.src, job.dst, sol.R, sol.t, 100.0);
-  const double e_odom = tz::error_metric(job.src, job.dst, Ro, to, 100.0);
-  if (e_teaser <= e_odom) {  // IcpLoopComputation.cc:1065-1068
-    for (int i = 0; i < 16; ++i) T_out[i] = (i == 15) ? 1.f : 0.f;
-    for (int a = 0; a < 3; ++a) {
-      for (int b = 0; b < 3; ++b) T_out[a * 4 + b] = (float)sol.R[a * 3 + b];
-      T_out[a * 4 + 3] = (float)sol.t[a];
+  hipStream_t st = ctx->stream;
+  std::vector<std::vector<int>> cliques((size_t)count);
+  {
+    std::vector<CliqueGraph> graphs((size_t)count, CliqueGraph{nullptr, 0, 0});
+    std::vector<int> on_host;
+    int on_device = 0, largest = 0;
+    for (int i = 0; i < count; ++i) {
+      const tz::BitGraph& g = jobs[i]->graph;
+      if (g.n == 0) continue;
+      if (g.bits.empty())
+        graphs[i] = CliqueGraph{jobs[i]->d_bits.p, g.n, g.words}, ++on_device, largest = std::max(largest, g.n);
+      else
+        on_host.push_back(i);
     }
-    *used = 1;
+    if (on_device && !greedy_clique_group(ctx->cfg.device, st, graphs.data(), count, cliques.data()))
+      return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: clique search over %d graphs (up to %d matches) "
+                  "failed on the device (%s)", on_device, largest, hipGetErrorString(hipGetLastError()));
+    // graphs the device path does not take (or reserved[4] = -1): the host search, pairs side by
+    // side; a pair with ten thousand matches also spreads its own starts over threads
+    parallel_for((int)on_host.size(), [&](int q) {
+      const tz::BitGraph& g = jobs[on_host[q]]->graph;
+      cliques[on_host[q]] = tz::greedy_clique(g, g.n >= 2048 ? 8 : 1);
+    });
   }
+  // rotation: small cliques on the host, the others together on the device
+  struct Work {
+    std::vector<double> cs, cd;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    bool solved = false;
+  };
+  std::vector<Work> W((size_t)count);
+  std::vector<int> small;
+  std::vector<RotJob> big;
+  for (int i = 0; i < count; ++i) {
+    n_clique[i] = (int)cliques[i].size();
+    if (cliques[i].size() <= 1) continue;
+    tz::clique_points(jobs[i]->src, jobs[i]->dst, cliques[i], &W[i].cs, &W[i].cd);
+    W[i].solved = true;
+    if (cliques[i].size() < 128)
+      small.push_back(i);
+    else
+      big.push_back(RotJob{&W[i].cs, &W[i].cd, W[i].R});
+  }
+  parallel_for((int)small.size(), [&](int q) {
+    Work& w = W[small[q]];
+    tz::clique_rotation_host(w.cs, w.cd, prm, w.R);
+  });
+  if (!big.empty() && !clique_rotation_group(ctx->cfg.device, st, big.data(), (int)big.size(), prm)) {
+    (void)hipStreamSynchronize(st);  // nothing may still read the buffers when the next group overwrites them
+    return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: rotation search over %d cliques failed on the "
+                "device (%s)", (int)big.size(), hipGetErrorString(hipGetLastError()));
+  }
+  parallel_for(count, [&](int i) {
+    if (jobs[i]->graph.n == 0) return;
+    Work& w = W[i];
+    if (w.solved) tz::clique_translation(w.cs, w.cd, w.R, prm, w.t);
+    double Ro[9], to[3];
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) Ro[a * 3 + b] = (double)guesses[i][a * 4 + b];
+      to[a] = (double)guesses[i][a * 4 + 3];
+    }
+    const double e_teaser = tz::error_metric(jobs[i]->src, jobs[i]->dst, w.R, w.t, 100.0);
+    const double e_odom = tz::error_metric(jobs[i]->src, jobs[i]->dst, Ro, to, 100.0);
+    if (e_teaser <= e_odom) {  // IcpLoopComputation.cc:1065-1068
+      float* T = T_out[i];
+      for (int q = 0; q < 16; ++q) T[q] = (q == 15) ? 1.f : 0.f;
+      for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) T[a * 4 + b] = (float)w.R[a * 3 + b];
+        T[a * 4 + 3] = (float)w.t[a];
+      }
+      used[i] = 1;
+    }
+  });
   return LGICP_OK;
 }
 
@@ -717,7 +894,13 @@ int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFea
   const int rc = teaser_prepare_device(ctx, src, tgt, &job);
   *n_matches = job.n_matches;
   if (rc != LGICP_OK) return rc;
-  return teaser_finish(ctx, job, guess, T_out, used, n_clique);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  teaser_prepare_collect(&job);
+  TeaserJob* jp = &job;
+  float T[1][16];
+  const int rc2 = teaser_finish_group(ctx, &jp, &guess, 1, T, used, n_clique);
+  if (rc2 == LGICP_OK) std::memcpy(T_out, T[0], sizeof(float) * 16);
+  return rc2;
 }
 
 }  // namespace lgicp_detail

@@ -248,6 +248,8 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
   for (auto& kv : ctx->scans) kv.second.free_device();
   ctx->reg.destroy();
+  ctx->teaser_slots.clear();  // device buffers: released while the context's device is current
+  if (ctx->matcher) ctx->matcher->release();
   delete ctx;
 }
 
@@ -553,104 +555,62 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
   } feats{feat_ptr};
   if (cfg.init_method == LGICP_INIT_TEASERPP) {
     // IcpLoopComputation.cc:528-531: never rejects; keeps the odometry guess unless the
-    // TEASER++ transform explains the descriptor matches at least as well.  The matches and
-    // their consistency graph come from the device one pair after the other; clique and
-    // rotation search are host work and run for a window of pairs on as many threads.
-    // The cost of a pair grows with the square of its clique, so pairs are handed out one
-    // by one: this thread produces (device work), up to 16 workers consume; at most `window`
-    // graphs or 1 GiB of them wait or are being solved at any time.
-    const int window = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    // TEASER++ transform explains the descriptor matches at least as well.  Pairs are taken in
+    // groups: matches and consistency graph pair by pair, then clique search and rotation search
+    // for the whole group together (their steps are latency-bound launches, which cost the same
+    // for one pair as for sixty-four).  Largest pairs first, so that the pairs of a group are of
+    // similar size and the buffers of the slots are sized once.
     const bool trace = std::getenv("LGICP_TRACE") != nullptr;  // diagnostics on stderr
-    struct Slot {
-      TeaserJob job;
-      int pair = -1;
-      size_t bytes = 0;
-    };
-    std::vector<Slot> slots((size_t)window);
-    std::vector<int> free_slots, ready;
-    for (int j = 0; j < window; ++j) free_slots.push_back(j);
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t held_bytes = 0;
-    bool closed = false;
-    std::atomic<int> rc_finish{LGICP_OK};
-    auto worker = [&]() {
-      // HIP's current device is per thread and starts at 0: the rotation search of large cliques
-      // allocates and launches from this thread
-      if (hipSetDevice(cfg.device) != hipSuccess) rc_finish.store(LGICP_E_HIP);
-      for (;;) {
-        int j;
-        {
-          std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return !ready.empty() || closed; });
-          if (ready.empty()) return;
-          j = ready.back();
-          ready.pop_back();
-        }
-        const int p = slots[j].pair;
-        const PairPlan& pp = bp.pairs[p];
-        float T0[16];
-        int used = 0, nc = 0;
-        const auto t_a = std::chrono::steady_clock::now();
-        const int rc = teaser_finish(ctx, slots[j].job, pp.guess, T0, &used, &nc);
-        if (rc != LGICP_OK) rc_finish.store(rc);
-        if (trace)
-          std::fprintf(stderr, "[lgicp] teaser pair %d: %d matches, clique %d, host %.1f ms\n", p,
-                       slots[j].job.n_matches, nc,
-                       1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count());
-        out[pp.cand].init_fitness = used ? (double)nc : 0.0;
-        std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
-        if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          held_bytes -= slots[j].bytes;
-          free_slots.push_back(j);
-        }
-        cv.notify_all();
-      }
-    };
-    std::vector<std::thread> pool;
-    for (int j = 0; j < window; ++j) pool.emplace_back(worker);
-    int rc_prepare = LGICP_OK;
-    // largest first: the host half of a pair grows steeply with its number of matches (five per
-    // source keypoint), and the submit ends when the slowest pair does
+    constexpr int kGroup = 64;
+    constexpr size_t kGroupBytes = 6ull << 30;  // bit matrices of a group
+    std::vector<std::shared_ptr<TeaserJob>>& slots = ctx->teaser_slots;
+    while ((int)slots.size() < kGroup) slots.push_back(std::make_shared<TeaserJob>());
     std::vector<int> by_size((size_t)n_pairs);
     for (int p = 0; p < n_pairs; ++p) by_size[p] = p;
     std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) {
       return feats[bp.pairs[a].src_cloud].idx.size() > feats[bp.pairs[b].src_cloud].idx.size();
     });
-    for (int q = 0; q < n_pairs && rc_prepare == LGICP_OK; ++q) {
-      const int p = by_size[q];
-      int j;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !free_slots.empty() && held_bytes < (1ull << 30); });
-        j = free_slots.back();
-        free_slots.pop_back();
+    int q = 0;
+    while (q < n_pairs) {
+      const auto t_a = std::chrono::steady_clock::now();
+      int g = 0;
+      size_t bytes = 0;
+      int group_pair[kGroup];
+      TeaserJob* jobs[kGroup];
+      const float* guesses[kGroup];
+      while (q < n_pairs && g < kGroup && bytes < kGroupBytes) {
+        const int p = by_size[q++];
+        const PairPlan& pp = bp.pairs[p];
+        const int rc = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], slots[g].get());
+        if (rc != LGICP_OK) return rc;
+        bytes += (size_t)slots[g]->graph.n * slots[g]->graph.words * sizeof(uint64_t);
+        group_pair[g] = p, jobs[g] = slots[g].get(), guesses[g] = pp.guess;
+        ++g;
       }
-      const PairPlan& pp = bp.pairs[p];
-      rc_prepare = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], &slots[j].job);
-      slots[j].pair = p;
-      slots[j].bytes = slots[j].job.graph.bits.size() * sizeof(uint64_t);
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        if (rc_prepare == LGICP_OK) {
-          held_bytes += slots[j].bytes;
-          ready.push_back(j);
-        } else {
-          free_slots.push_back(j);
-        }
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      for (int j = 0; j < g; ++j) teaser_prepare_collect(jobs[j]);
+      const auto t_b = std::chrono::steady_clock::now();
+      float T0[kGroup][16];
+      int used[kGroup], nc[kGroup];
+      const int rc = teaser_finish_group(ctx, jobs, guesses, g, T0, used, nc);
+      if (rc != LGICP_OK) return rc;
+      for (int j = 0; j < g; ++j) {
+        const int p = group_pair[j];
+        out[bp.pairs[p].cand].init_fitness = used[j] ? (double)nc[j] : 0.0;
+        std::memcpy(h_pairs[p].guess, T0[j], sizeof(T0[j]));
+        if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0[j], sizeof(T0[j]));
       }
-      cv.notify_all();
+      if (trace)
+        std::fprintf(stderr, "[lgicp] teaser group of %d pairs (%d-%d matches): graphs %.1f ms, solve %.1f ms\n", g,
+                     jobs[g - 1]->n_matches, jobs[0]->n_matches,
+                     1e3 * std::chrono::duration<double>(t_b - t_a).count(),
+                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
     }
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      closed = true;
-    }
-    cv.notify_all();
-    for (std::thread& t : pool) t.join();
-    if (rc_prepare != LGICP_OK) return rc_prepare;
-    if (rc_finish.load() != LGICP_OK) return rc_finish.load();
+    // the slots keep their bit matrices for the next submit unless they have grown large
+    size_t held = 0;
+    for (auto& sl : slots) held += sl->d_bits.cap * sizeof(unsigned long long);
+    if (held > (8ull << 30))
+      for (auto& sl : slots) sl->d_bits.release();
   }
   for (int p = 0; p < n_pairs && cfg.init_method == LGICP_INIT_FEATURES; ++p) {
     const PairPlan& pp = bp.pairs[p];

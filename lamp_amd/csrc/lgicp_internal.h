@@ -27,6 +27,8 @@ namespace lgicp_detail {
 inline std::string g_create_error;
 
 struct CloudFeatures;
+struct TeaserJob;
+struct MatcherDev;
 
 struct DevBlock {  // one device allocation shared by the keyframes registered in one call
   char* p = nullptr;
@@ -264,6 +266,9 @@ struct lgicp_ctx {
   SlotThreads helpers;
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
   Registry reg;                  // keyframe registration
+  // bit matrices and matches of the pairs of a TEASERPP group, reused from submit to submit
+  std::vector<std::shared_ptr<lgicp_detail::TeaserJob>> teaser_slots;
+  std::shared_ptr<lgicp_detail::MatcherDev> matcher;
 };
 
 namespace lgicp_detail {
@@ -274,6 +279,11 @@ struct CloudFeatures {
   std::vector<int> idx;       // keypoint indices, ascending
   std::vector<float> xyz;     // [k][3]
   std::vector<float> feat;    // [k][33]
+  // the same on the device (one allocation, released with the last copy of this struct):
+  // descriptors and keypoint coordinates stay where the matcher reads them
+  std::shared_ptr<DevBlock> dev;
+  const float* d_feat = nullptr;  // [k][33]
+  const float* d_kxyz = nullptr;  // [k][3]
 };
 // Uploads `count` clouds and builds, on the device, their spatial index and (derive) what depends
 // on a keyframe alone: covariances from the normals, records, ExtractNormals, NormalizePCloud
@@ -288,8 +298,8 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
 int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                         const float guess[16], float T_out[16], int* used, int* n_matches,
                         int* n_clique);
-// the same in two halves: the device half of one pair can run while the host halves of earlier
-// pairs are still being solved on other threads
+// the same in two halves: matches and consistency graph pair by pair, then clique, rotation and
+// translation for a group of pairs together
 struct TeaserJob {
   int n_matches = 0;
   std::vector<double> src, dst;  // matched keypoints, [n_matches][3]
@@ -297,20 +307,45 @@ struct TeaserJob {
   // clique search runs on the host, otherwise the bit matrix lives in d_bits alone
   lgicp::teaser::BitGraph graph;
   DevBuf<unsigned long long> d_bits;  // [graph.n][graph.words], reused from pair to pair
+  DevBuf<double> d_sd;                // matched keypoints on the device: src [n][3], then dst [n][3]
+  double* h_sd = nullptr;             // pinned landing area of d_sd
+  size_t h_sd_cap = 0;
   TeaserJob() = default;
   TeaserJob(const TeaserJob&) = delete;
   TeaserJob& operator=(const TeaserJob&) = delete;
-  ~TeaserJob() { d_bits.release(); }
+  ~TeaserJob() {
+    d_bits.release(), d_sd.release();
+    if (h_sd) (void)hipHostFree(h_sd);
+  }
+};
+// buffers of the descriptor matcher, reused from pair to pair (work of successive pairs is
+// ordered by the context's stream)
+struct MatcherDev {
+  DevBuf<float> part_d;
+  DevBuf<int> part_i, nn;
+  void release() { part_d.release(), part_i.release(), nn.release(); }
 };
 // teaser::greedy_clique on a bit matrix in device memory (teaser_graph.hip): core numbers and the
 // windows of starts run on `st`; false when the device refuses
 bool greedy_clique_device(int device, hipStream_t st, const unsigned long long* d_bits, int n, int words,
                           std::vector<int>* clique);
+// the same for `count` graphs at once (every launch carries a step of all of them); entries with
+// n == 0 are skipped and get an empty clique
+struct CliqueGraph {
+  const unsigned long long* d_bits;
+  int n, words;
+};
+bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* graphs, int count,
+                         std::vector<int>* cliques);
 int clique_device_max_vertices();
+// first half: enqueues matcher and consistency graph of one pair on the context's stream and
+// returns; teaser_prepare_collect (after the stream has been synchronised) moves the matched
+// keypoints into job->src / job->dst
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                           TeaserJob* job);
-int teaser_finish(lgicp_ctx* ctx, const TeaserJob& job, const float guess[16], float T_out[16],
-                  int* used, int* n_clique);
+void teaser_prepare_collect(TeaserJob* job);
+int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
+                        float (*T_out)[16], int* used, int* n_clique);
 
 // device address of the static scratch array behind lgicp_nn_search_static, looked up once per
 // device; `device` must be the current device

@@ -393,6 +393,8 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   out->idx.clear();
   out->xyz.clear();
   out->feat.clear();
+  out->dev.reset();
+  out->d_feat = out->d_kxyz = nullptr;
   if (n <= 0) return LGICP_OK;
   const lgicp_config& cfg = ctx->cfg;
   if (cfg.harris_response != 1 || cfg.harris_refine || !cfg.harris_suppression)
@@ -424,8 +426,12 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   float4* d_kp = d.alloc<float4>(k);
   unsigned char* d_need = d.alloc<unsigned char>((size_t)n);
   float* d_spfh = d.alloc<float>((size_t)n * 33);
-  float* d_out = d.alloc<float>(k * 33);
+  // descriptors and keypoint coordinates stay on the device for the matcher
+  auto block = std::make_shared<DevBlock>();
+  if (hipMalloc((void**)&block->p, sizeof(float) * 36 * k) != hipSuccess) block->p = nullptr;
+  float* d_out = reinterpret_cast<float*>(block->p);
   if (!d_kp || !d_need || !d_spfh || !d_out) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, hipMemcpyAsync(d_out + 33 * k, out->xyz.data(), sizeof(float) * 3 * k, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp.data(), sizeof(float4) * k, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemsetAsync(d_spfh, 0, sizeof(float) * (size_t)n * 33, st));
   const float fr2 = (float)(cfg.sac_features_radius * cfg.sac_features_radius);
@@ -433,6 +439,9 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   out->feat.resize(33 * k);
   HIP_TRY(ctx, hipMemcpyAsync(out->feat.data(), d_out, sizeof(float) * 33 * k, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  out->dev = block;
+  out->d_feat = d_out;
+  out->d_kxyz = d_out + 33 * k;
   return LGICP_OK;
 }
 

@@ -450,6 +450,32 @@ inline void clique_rotation_host(const std::vector<double>& cs, const std::vecto
   gnc_rotation(st, dt, p, R);
 }
 
+// the matches of a clique, [m][3] each
+inline void clique_points(const std::vector<double>& src, const std::vector<double>& dst,
+                          const std::vector<int>& clique, std::vector<double>* cs, std::vector<double>* cd) {
+  const int m = (int)clique.size();
+  cs->resize((size_t)3 * m), cd->resize((size_t)3 * m);
+  for (int i = 0; i < m; ++i)
+    for (int c = 0; c < 3; ++c) {
+      (*cs)[3 * i + c] = src[3 * clique[i] + c];
+      (*cd)[3 * i + c] = dst[3 * clique[i] + c];
+    }
+}
+
+// per-axis truncated-least-squares vote over the clique's matches under rotation R
+inline void clique_translation(const std::vector<double>& cs, const std::vector<double>& cd, const double R[9],
+                               const Params& p, double t[3]) {
+  const int m = (int)(cs.size() / 3);
+  std::vector<double> v(m);
+  for (int a = 0; a < 3; ++a) {
+    for (int i = 0; i < m; ++i) {
+      const double* x = &cs[3 * i];
+      v[i] = cd[3 * i + a] - (R[a * 3] * x[0] + R[a * 3 + 1] * x[1] + R[a * 3 + 2] * x[2]);
+    }
+    t[a] = tls_scalar(v, p.cbar2 * p.noise_bound);
+  }
+}
+
 // rotation and translation from the matches of the clique (src/dst are [n][3]); `rotation` is
 // clique_rotation_host or a drop-in that does the same sums elsewhere
 template <class RotationFn>
@@ -459,21 +485,10 @@ inline Solution solve_on_clique(const std::vector<double>& src, const std::vecto
   s.clique = std::move(clique);
   const int m = (int)s.clique.size();
   if (m <= 1) return s;
-  std::vector<double> cs((size_t)3 * m), cd((size_t)3 * m);
-  for (int i = 0; i < m; ++i)
-    for (int c = 0; c < 3; ++c) {
-      cs[3 * i + c] = src[3 * s.clique[i] + c];
-      cd[3 * i + c] = dst[3 * s.clique[i] + c];
-    }
+  std::vector<double> cs, cd;
+  clique_points(src, dst, s.clique, &cs, &cd);
   rotation(cs, cd, p, s.R);
-  std::vector<double> v(m);
-  for (int a = 0; a < 3; ++a) {
-    for (int i = 0; i < m; ++i) {
-      const double* x = &cs[3 * i];
-      v[i] = cd[3 * i + a] - (s.R[a * 3] * x[0] + s.R[a * 3 + 1] * x[1] + s.R[a * 3 + 2] * x[2]);
-    }
-    s.t[a] = tls_scalar(v, p.cbar2 * p.noise_bound);
-  }
+  clique_translation(cs, cd, s.R, p, s.t);
   s.valid = true;
   return s;
 }

@@ -1,18 +1,24 @@
 // teaser_graph.hip — the graph half of the TEASERPP initialisation on the device
 // (IcpLoopComputation::GetTeaserInitialAlignment, loop_closure/src/IcpLoopComputation.cc:996-1054 ->
 // teaser::RobustRegistrationSolver with PMC_HEU inlier selection): core numbers of the
-// scale-consistency graph and the greedy clique heuristic of teaser.h, on the bit matrix the
-// consistency_graph_kernel left in device memory (it never travels to the host).
+// scale-consistency graph and the greedy clique heuristic of teaser.h, on the bit matrices the
+// consistency_graph_kernel left in device memory (they never travel to the host), for a whole
+// group of candidate pairs at a time.
+//
+// Both halves are chains of small dependent steps (one launch per H-operator round, one per window
+// of clique starts, each lasting as long as its slowest wave), so one pair alone leaves the GPU
+// idle; every launch here therefore carries the step of all pairs of the group, and a step costs
+// the slowest pair's latency once per group.
 //
 // Core numbers: the H-operator iteration (Lu, Zhou, Zhang, Stanley 2016: starting from the degrees,
 // c(v) <- H-index of the neighbours' values converges to the core numbers).  Every round is one
-// fully parallel launch (one wave per vertex, the previous round's values in LDS) and a few tens of
-// rounds suffice on these graphs, where level-by-level peeling pays a grid-wide step for each of
-// the thousands of distinct core values and bucket peeling is sequential.  Core numbers are a
-// property of the graph, so the result equals the host's bucket peeling (teaser::core_bounds)
+// fully parallel launch (one wave per four vertices, the previous round's values in LDS) and a few
+// tens of rounds suffice on these graphs, where level-by-level peeling pays a grid-wide step for
+// each of the thousands of distinct core values and bucket peeling is sequential.  Core numbers are
+// a property of the graph, so the result equals the host's bucket peeling (teaser::core_bounds)
 // entry by entry.
 //
-// clique_starts_kernel: one wave per start of the greedy heuristic (teaser::greedy_clique's
+// clique_starts_group_kernel: one wave per start of the greedy heuristic (teaser::greedy_clique's
 // start_from): candidates = neighbours of the start vertex whose bound exceeds the best size so
 // far, kept as a bit set in LDS; repeatedly the first candidate in preference order (bound, then
 // id, descending) joins the clique and the set is intersected with its row; the start gives up
@@ -22,6 +28,7 @@
 // evaluated again against the new size) and obtains the serial algorithm's clique bit for bit.
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,9 +40,31 @@
 
 namespace lgicp {
 
+// One pair's graph as the kernels see it.  Per-vertex arrays of all pairs of a group share one
+// allocation each; a pair's part starts at c_off (a multiple of 8 elements, padding zeroed).
+struct GraphDev {
+  const unsigned long long* bits;  // [n][words]
+  int n, words;
+  int c_off;     // first element of the pair's per-vertex arrays
+  int w_off;     // first word of its eligibility set
+  int mc;        // best clique size so far
+  int list_off;  // first element of the member-list slots this round's starts may fill
+  int n_pad;     // elements per slot
+  int nbits;     // bits of a per-vertex value (values < n <= 2^nbits)
+  int stride;    // words per bit plane (words rounded up to even)
+  int pl_off;    // first word of the pair's bit planes
+};
+
+constexpr int HX_ROUNDS = 8;        // H-operator rounds between two looks at the flags
+constexpr int HX_VPW = 16;          // vertices per wave and round
+constexpr int HX_VPB = 4 * HX_VPW;  // per workgroup of four waves: the 64 vertices of one bit-set word
+constexpr int CLQ_MAX_WORDS = 1024;  // 65536 matches
+constexpr int CLQ_SLOTS = 16;        // member lists a pair can keep per round (+1 for a start run alone)
+constexpr int CLQ_LIST_CAP = 4096;   // members a start keeps in LDS
+
 // degree of every vertex: one wave per row of the bit matrix
 __global__ __launch_bounds__(256) void graph_degree_kernel(const unsigned long long* __restrict__ bits, int n,
-                                                           int words, int* __restrict__ deg) {
+                                                           int words, unsigned short* __restrict__ deg) {
   const int lane = threadIdx.x & 63;
   const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (v >= n) return;  // wave-uniform
@@ -44,45 +73,84 @@ __global__ __launch_bounds__(256) void graph_degree_kernel(const unsigned long l
   for (int w = lane; w < words; w += 64) d += __builtin_popcountll(r[w]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
-  if (lane == 0) deg[v] = d;
+  if (lane == 0) deg[v] = (unsigned short)d;  // d < n <= 65536
 }
 
-// One round of the H-operator: c_new(v) = the largest h such that at least h neighbours u of v
-// have c_old(u) >= h (never more than c_old(v)).  The values of a round come from the round
-// before alone, so the rounds are deterministic; `*changed` is raised when any value moved.
-// dynamic LDS: c_old as n unsigned shorts (n <= 65536, so every value fits).
-__global__ __launch_bounds__(256) void core_hindex_kernel(const unsigned long long* __restrict__ bits, int n,
-                                                          int words, const int* __restrict__ c_old,
-                                                          int* __restrict__ c_new, int* __restrict__ changed) {
-  extern __shared__ unsigned short cs[];
-  for (int i = threadIdx.x; i < n; i += 256) cs[i] = (unsigned short)c_old[i];
-  if (threadIdx.x == 0) cs[n] = 0;  // sentinel for missing neighbours
+// Bit planes of the per-vertex values of every pair: bit v of plane b = bit b of value(v).
+// blk[g] = (pair, first vertex) of one 64-vertex group; one wave per group.
+__global__ __launch_bounds__(256) void value_planes_kernel(const GraphDev* __restrict__ graphs,
+                                                           const int2* __restrict__ blk, int n_groups,
+                                                           const unsigned short* __restrict__ c,
+                                                           unsigned long long* __restrict__ planes) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g >= n_groups) return;  // wave-uniform
+  const int2 b = blk[g];
+  const GraphDev G = graphs[b.x];
+  const int v = b.y + lane;
+  const int val = v < G.n ? (int)c[G.c_off + v] : 0;
+  for (int q = 0; q < G.nbits; ++q) {
+    const unsigned long long m = __ballot((val >> q) & 1);
+    if (lane == 0) planes[(size_t)G.pl_off + (size_t)q * G.stride + (b.y >> 6)] = m;
+  }
+}
+
+// One round of the H-operator for every pair of the group: c_new(v) = the largest h such that at
+// least h neighbours u of v have c_old(u) >= h (never more than c_old(v)).  The values of a round
+// come from the round before alone, so the rounds are deterministic.  blk[b] = (pair, first vertex)
+// of workgroup b, which owns the 64 vertices of one word; flags[pair][r] is raised when a value of
+// the pair moved in round r, and a pair whose previous round moved nothing is skipped (both plane
+// arrays hold its fixed point by then).
+// The old values live in LDS as bit planes, and "neighbours with a value >= h" is counted bit-set
+// wise: per word of the row, the bit-sliced comparison of 64 values with h (a few operations per
+// plane), an AND and a population count - a cost per vertex that depends on the size of the graph
+// and not on its density, against one LDS gather per neighbour when the values are kept as numbers
+// (these graphs have thousands of neighbours per vertex).
+// dynamic LDS: nbits planes of `stride` words.
+__global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* __restrict__ graphs,
+                                                                const int2* __restrict__ blk,
+                                                                const unsigned long long* __restrict__ planes_old,
+                                                                unsigned long long* __restrict__ planes_new,
+                                                                unsigned short* __restrict__ c_out,
+                                                                int* __restrict__ flags, int r) {
+  extern __shared__ __align__(16) unsigned long long pl[];
+  __shared__ unsigned short res[HX_VPB];
+  const int2 b = blk[blockIdx.x];
+  const int p = b.x;
+  if (r > 0 && flags[p * HX_ROUNDS + r - 1] == 0) return;  // uniform over the workgroup
+  const GraphDev G = graphs[p];
+  const int n = G.n, words = G.words, nbits = G.nbits, stride = G.stride;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(planes_old + G.pl_off);
+    uint4* dst = reinterpret_cast<uint4*>(pl);
+    const int nv = (nbits * stride) >> 1;  // stride is even
+    for (int i = threadIdx.x; i < nv; i += 256) dst[i] = src[i];
+  }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int v = blockIdx.x * 4 + wave; v < n; v += gridDim.x * 4) {  // wave-uniform
-    const int cv = (int)cs[v];
-    const unsigned long long* r = bits + (size_t)v * words;
-    // neighbours whose value is at least h.  Each lane walks the bits of its words rotated by
-    // its lane number: in a dense row the lanes would otherwise all sit at the same bit of 64
-    // consecutive words, 64 values that share one LDS bank.
-    auto count_ge = [&](int h) {  // h >= 1
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int q = 0; q < HX_VPW; ++q) {
+    const int v = b.y + wave * HX_VPW + q;  // wave-uniform
+    if (v >= n) {
+      if (lane == 0) res[wave * HX_VPW + q] = 0;
+      continue;
+    }
+    // the vertex's own value: lane q' fetches bit q' of it
+    const int cv = (int)__ballot(lane < nbits && ((pl[(lane < nbits ? lane : 0) * stride + (v >> 6)] >> (v & 63)) & 1ull));
+    const unsigned long long* row = G.bits + (size_t)v * words;
+    auto count_ge = [&](int h) {  // neighbours whose value is at least h
       int c = 0;
       for (int w = lane; w < words; w += 64) {
-        unsigned long long m = r[w];
-        m = (m >> lane) | (m << ((64 - lane) & 63));
-        const int base = w << 6;
-        while (m) {
-          // four neighbours per trip, so that four LDS reads are in flight at a time; a missing
-          // one reads the sentinel cs[n] = 0, which never reaches h
-          int u[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            u[q] = m ? base + ((__builtin_ctzll(m) + lane) & 63) : n;
-            m &= m - 1;
+        const unsigned long long rw = row[w];
+        unsigned long long gt = 0, eq = ~0ull;
+        for (int k = nbits - 1; k >= 0; --k) {
+          const unsigned long long P = pl[k * stride + w];
+          if ((h >> k) & 1) {  // wave-uniform
+            eq &= P;
+          } else {
+            gt |= eq & P;
+            eq &= ~P;
           }
-          const int a0 = cs[u[0]], a1 = cs[u[1]], a2 = cs[u[2]], a3 = cs[u[3]];
-          c += (a0 >= h) + (a1 >= h) + (a2 >= h) + (a3 >= h);
         }
+        c += __builtin_popcountll(rw & (gt | eq));
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
@@ -109,43 +177,58 @@ __global__ __launch_bounds__(256) void core_hindex_kernel(const unsigned long lo
       h = lo;
     }
     if (lane == 0) {
-      c_new[v] = h;
-      if (h != cv) *changed = 1;
+      res[wave * HX_VPW + q] = (unsigned short)h;
+      c_out[G.c_off + v] = (unsigned short)h;
+      if (h != cv) flags[p * HX_ROUNDS + r] = 1;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {  // the planes of the 64 new values
+    const int val = (int)res[lane];
+    for (int k = 0; k < nbits; ++k) {
+      const unsigned long long m = __ballot((val >> k) & 1);
+      if (lane == 0) planes_new[(size_t)G.pl_off + (size_t)k * stride + (b.y >> 6)] = m;
     }
   }
 }
 
-// K = core number + 1: the bound on the size of a clique through a vertex
-__global__ __launch_bounds__(256) void core_bound_kernel(const int* __restrict__ c, int n, int* __restrict__ K) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) K[i] = c[i] + 1;
-}
-
-// elig bit u = K[u] > mc
-__global__ __launch_bounds__(256) void clique_eligible_kernel(const int* __restrict__ K, int n, int words,
-                                                              int mc, unsigned long long* __restrict__ elig) {
+// elig bit u = (core number of u) + 1 > mc, for every pair (blockIdx.y); also hands the pair's
+// list slots out afresh (tickets[2 p] = slots taken, tickets[2 p + 1] = lowest improving start so far)
+__global__ __launch_bounds__(256) void clique_eligible_group_kernel(const GraphDev* __restrict__ graphs,
+                                                                    const unsigned short* __restrict__ c,
+                                                                    unsigned long long* __restrict__ elig,
+                                                                    int* __restrict__ tickets) {
+  const GraphDev G = graphs[blockIdx.y];
   const int w = blockIdx.x * 256 + threadIdx.x;
-  if (w >= words) return;
+  if (w == 0) tickets[2 * blockIdx.y] = 0, tickets[2 * blockIdx.y + 1] = INT_MAX;
+  if (w >= G.words) return;
+  const unsigned short* cp = c + G.c_off + w * 64;
   unsigned long long m = 0;
-  for (int b = 0; b < 64; ++b) {
-    const int u = w * 64 + b;
-    if (u < n && K[u] > mc) m |= 1ull << b;
-  }
-  elig[w] = m;
+  const int left = G.n - w * 64;  // vertices of this word
+  for (int b = 0; b < 64 && b < left; ++b)
+    if ((int)cp[b] + 1 > G.mc) m |= 1ull << b;
+  elig[G.w_off + w] = m;
 }
 
-constexpr int CLQ_MAX_WORDS = 1024;  // 65536 matches
-
-// one wave per start; out_size[s] = members found besides the start vertex (0: cannot beat mc);
-// out_list (optional, single-start launches only) receives those members in the order they joined
-__global__ __launch_bounds__(64) void clique_starts_kernel(
-    const unsigned long long* __restrict__ bits, int n, int words, const int* __restrict__ pref,
-    const unsigned long long* __restrict__ elig, const int* __restrict__ starts, int mc,
-    int* __restrict__ out_size, int* __restrict__ out_list) {
+// One wave per start.  starts[s] = (pair, start vertex); out[2 s] = members found besides the start
+// vertex (0: cannot beat the pair's mc), out[2 s + 1] = the list slot that holds them in the order
+// they joined (-1: none; the host then runs the start once more on its own with kDirect, which
+// writes the members straight into the pair's extra slot).
+template <bool kDirect>
+__global__ __launch_bounds__(64) void clique_starts_group_kernel(
+    const GraphDev* __restrict__ graphs, const unsigned short* __restrict__ pref_all,
+    const unsigned long long* __restrict__ elig_all, const int2* __restrict__ starts,
+    int* __restrict__ out, unsigned short* __restrict__ lists, int* __restrict__ tickets) {
   __shared__ unsigned long long cand[CLQ_MAX_WORDS];
+  __shared__ unsigned short lst[kDirect ? 8 : CLQ_LIST_CAP];
   const int s = blockIdx.x, lane = threadIdx.x;
-  const int v = starts[s];
-  const unsigned long long* rv = bits + (size_t)v * words;
+  const int2 sv = starts[s];
+  const GraphDev G = graphs[sv.x];
+  const int v = sv.y, n = G.n, words = G.words, mc = G.mc;
+  const unsigned short* pref = pref_all + G.c_off;
+  const unsigned long long* elig = elig_all + G.w_off;
+  unsigned short* const direct = lists + (size_t)G.list_off + (size_t)CLQ_SLOTS * G.n_pad;
+  const unsigned long long* rv = G.bits + (size_t)v * words;
   int np = 0;
   for (int w = lane; w < words; w += 64) {
     const unsigned long long x = rv[w] & elig[w];
@@ -157,12 +240,11 @@ __global__ __launch_bounds__(64) void clique_starts_kernel(
   __syncthreads();
   int size = 0;
   if (np > mc) {
-    int* const list = out_list;
     int at = 0;
     while (at < n) {  // every pass advances `at`: at most n / 64 + clique size passes
       // the first candidate in preference order from `at` on
       const int idx = at + lane;
-      const int u = idx < n ? pref[idx] : -1;
+      const int u = idx < n ? (int)pref[idx] : -1;
       const bool hit = u >= 0 && ((cand[u >> 6] >> (u & 63)) & 1ull);
       const unsigned long long m = __ballot(hit);
       if (m == 0) {
@@ -172,9 +254,14 @@ __global__ __launch_bounds__(64) void clique_starts_kernel(
       const int first = __builtin_ctzll(m);
       const int pick = __builtin_amdgcn_readlane(u, first);
       at += first + 1;
-      if (list && lane == 0) list[size] = pick;
+      if (lane == 0) {
+        if (kDirect)
+          direct[size] = (unsigned short)pick;
+        else if (size < CLQ_LIST_CAP)
+          lst[size] = (unsigned short)pick;
+      }
       ++size;
-      const unsigned long long* r = bits + (size_t)pick * words;
+      const unsigned long long* r = G.bits + (size_t)pick * words;
       int left = 0;
       __syncthreads();  // all lanes have read cand for the ballot above
       for (int w = lane; w < words; w += 64) {
@@ -194,7 +281,29 @@ __global__ __launch_bounds__(64) void clique_starts_kernel(
       if (left == 0) break;
     }
   }
-  if (lane == 0) out_size[s] = size;
+  int ticket = -1;
+  if (size > 0 && size + 1 > mc) {
+    if (kDirect) {
+      ticket = CLQ_SLOTS;
+    } else if (size <= CLQ_LIST_CAP) {
+      // The host wants the members of the pair's first improving start in window order only: a
+      // start keeps its list when no start before it has improved so far (the first one always
+      // passes this test; the others that do are few, a sequence of running minima).
+      int t = CLQ_SLOTS;
+      if (lane == 0 && atomicMin(&tickets[2 * sv.x + 1], s) > s) t = atomicAdd(&tickets[2 * sv.x], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t < CLQ_SLOTS) {
+        __syncthreads();  // lane 0's list entries
+        unsigned short* dst = lists + (size_t)G.list_off + (size_t)t * G.n_pad;
+        for (int i = lane; i < size; i += 64) dst[i] = lst[i];
+        ticket = t;
+      }
+    }
+  }
+  if (lane == 0) {
+    out[2 * s] = size;
+    out[2 * s + 1] = ticket;
+  }
 }
 
 }  // namespace lgicp
@@ -202,24 +311,50 @@ __global__ __launch_bounds__(64) void clique_starts_kernel(
 namespace lgicp_detail {
 
 namespace {
-// buffers of the clique search, one set per host thread and device, reused from pair to pair
-struct CliqueSearchDev {
+struct PinBuf {  // grow-only pinned host array
+  char* p = nullptr;
+  size_t cap = 0;
+  bool reserve(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
+      p = nullptr;
+      return false;
+    }
+    cap = want;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+  }
+};
+
+// buffers of the clique search, one set per host thread and device, reused from group to group
+struct CliqueGroupDev {
   int device = -1;
-  DevBuf<int> K, pref, starts, sizes, lists, cbuf, flags;
-  DevBuf<unsigned long long> elig;
+  DevBuf<unsigned short> c, pref, lists;
+  DevBuf<unsigned long long> elig, planes_a, planes_b;
+  DevBuf<lgicp::GraphDev> table;
+  DevBuf<int2> blk, starts;
+  DevBuf<int> flags, out, tickets;
+  PinBuf h_up, h_down;
   void release() {
     if (device >= 0) {
       int cur = -1;
       (void)hipGetDevice(&cur);
       if (cur != device) (void)hipSetDevice(device);
-      K.release(), pref.release(), starts.release(), sizes.release(), lists.release(), cbuf.release();
-      flags.release();
-      elig.release();
+      c.release(), pref.release(), lists.release(), elig.release(), table.release();
+      planes_a.release(), planes_b.release();
+      blk.release(), starts.release(), flags.release(), out.release(), tickets.release();
+      h_up.release(), h_down.release();
       if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
     device = -1;
   }
-  ~CliqueSearchDev() { release(); }
+  ~CliqueGroupDev() { release(); }
 };
 constexpr int kMaxWindow = 65536;
 }  // namespace
@@ -228,137 +363,292 @@ constexpr int kMaxWindow = 65536;
 // in LDS (128 KiB at 65536 vertices, the size the consistency graph is capped at anyway)
 int clique_device_max_vertices() { return 65536; }
 
-// teaser::greedy_clique on a bit matrix in device memory.  Returns false when the device
-// refuses; *clique comes back sorted ascending, equal to the host function's result.
-bool greedy_clique_device(int device, hipStream_t st, const unsigned long long* d_bits, int n, int words,
-                          std::vector<int>* clique) {
-  clique->clear();
-  if (n <= 0) return true;
-  if (n > clique_device_max_vertices() || words > lgicp::CLQ_MAX_WORDS) return false;
-  thread_local CliqueSearchDev B;
+// teaser::greedy_clique on `count` bit matrices in device memory, all of them advancing together.
+// Entries with n == 0 are skipped.  Returns false when the device refuses; cliques[i] comes back
+// sorted ascending, equal to the host function's result for graph i.
+bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int count, std::vector<int>* cliques) {
+  using lgicp::GraphDev;
+  for (int i = 0; i < count; ++i) cliques[i].clear();
+  std::vector<int> ids;
+  for (int i = 0; i < count; ++i) {
+    if (gr[i].n <= 0) continue;
+    if (gr[i].n > clique_device_max_vertices() || gr[i].words > lgicp::CLQ_MAX_WORDS ||
+        gr[i].words != (gr[i].n + 63) / 64)
+      return false;
+    ids.push_back(i);
+  }
+  const int P = (int)ids.size();
+  if (P == 0) return true;
+  thread_local CliqueGroupDev B;
   if (B.device != device) {
     B.release();
     if (hipSetDevice(device) != hipSuccess) return false;
     B.device = device;
   }
-  if (B.K.reserve((size_t)n) != hipSuccess || B.pref.reserve((size_t)n) != hipSuccess ||
-      B.starts.reserve(kMaxWindow) != hipSuccess ||
-      B.sizes.reserve(kMaxWindow) != hipSuccess || B.elig.reserve((size_t)words) != hipSuccess ||
-      B.lists.reserve((size_t)n) != hipSuccess)
-    return false;
   const bool trace = std::getenv("LGICP_TRACE") != nullptr;
   const auto t_0 = std::chrono::steady_clock::now();
   auto ms_since = [&](std::chrono::steady_clock::time_point t) {
     return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
   };
-  // ---- core numbers ---------------------------------------------------------------------------
-  const size_t lds_bytes = sizeof(unsigned short) * ((size_t)n + 2);
+  // ---- layout ----------------------------------------------------------------------------------
+  std::vector<GraphDev> tab((size_t)P);
+  std::vector<size_t> list_base((size_t)P);
+  size_t total_c = 0, total_w = 0, total_l = 0, total_blk = 0, total_pl = 0, max_planes = 0;
+  int max_n = 0, max_words = 0;
+  for (int p = 0; p < P; ++p) {
+    const CliqueGraph& g = gr[ids[p]];
+    GraphDev& t = tab[p];
+    t.bits = g.d_bits;
+    t.n = g.n, t.words = g.words;
+    t.n_pad = ((g.n + 7) & ~7) + 8;
+    t.c_off = (int)total_c, t.w_off = (int)total_w;
+    t.mc = 0, t.list_off = 0;
+    t.nbits = 1;
+    while ((1 << t.nbits) < g.n) ++t.nbits;  // values are at most n - 1
+    t.stride = (g.words + 1) & ~1;
+    t.pl_off = (int)total_pl;
+    total_pl += (size_t)t.nbits * t.stride;
+    max_planes = std::max(max_planes, (size_t)t.nbits * t.stride);
+    list_base[p] = total_l;
+    total_c += (size_t)t.n_pad;
+    total_w += (size_t)g.words;
+    total_l += (size_t)2 * (lgicp::CLQ_SLOTS + 1) * t.n_pad;
+    total_blk += (size_t)(g.n + lgicp::HX_VPB - 1) / lgicp::HX_VPB;
+    max_n = std::max(max_n, g.n), max_words = std::max(max_words, g.words);
+  }
+  if (total_l > (size_t)INT_MAX || total_c > (size_t)INT_MAX || total_pl > (size_t)INT_MAX) return false;
+  if (B.c.reserve(total_c) != hipSuccess || B.planes_a.reserve(total_pl) != hipSuccess ||
+      B.planes_b.reserve(total_pl) != hipSuccess ||
+      B.pref.reserve(total_c) != hipSuccess || B.lists.reserve(total_l) != hipSuccess ||
+      B.elig.reserve(total_w) != hipSuccess || B.table.reserve((size_t)P) != hipSuccess ||
+      B.blk.reserve(total_blk) != hipSuccess || B.flags.reserve((size_t)P * lgicp::HX_ROUNDS) != hipSuccess ||
+      B.tickets.reserve((size_t)2 * P) != hipSuccess)
+    return false;
+  const size_t tab_bytes = sizeof(GraphDev) * (size_t)P;
+  const size_t up_fixed = tab_bytes + sizeof(int2) * total_blk;
+  if (!B.h_up.reserve(std::max(up_fixed, tab_bytes + sizeof(unsigned short) * total_c)) ||
+      !B.h_down.reserve(std::max(sizeof(unsigned short) * total_c, sizeof(int) * (size_t)P * lgicp::HX_ROUNDS)))
+    return false;
+  auto upload_table = [&]() {
+    std::memcpy(B.h_up.p, tab.data(), tab_bytes);
+    return hipMemcpyAsync(B.table.p, B.h_up.p, tab_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+  };
+  // ---- core numbers ----------------------------------------------------------------------------
+  if (hipMemsetAsync(B.c.p, 0, sizeof(unsigned short) * total_c, st) != hipSuccess ||
+      hipMemsetAsync(B.planes_a.p, 0, sizeof(unsigned long long) * total_pl, st) != hipSuccess ||
+      hipMemsetAsync(B.planes_b.p, 0, sizeof(unsigned long long) * total_pl, st) != hipSuccess || !upload_table())
+    return false;
+  for (int p = 0; p < P; ++p)
+    hipLaunchKernelGGL(lgicp::graph_degree_kernel, dim3((tab[p].n + 3) / 4), dim3(256), 0, st, tab[p].bits,
+                       tab[p].n, tab[p].words, B.c.p + tab[p].c_off);
+  const size_t lds_bytes = sizeof(unsigned long long) * max_planes;
   static std::once_flag attr_once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(attr_once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(lgicp::core_hindex_kernel),
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 64);
   });
   if (attr_rc != hipSuccess) return false;
-  constexpr int kRoundsPerCheck = 8;
-  if (B.cbuf.reserve((size_t)2 * n) != hipSuccess || B.flags.reserve(kRoundsPerCheck) != hipSuccess) return false;
-  int* c_a = B.cbuf.p;
-  int* c_b = B.cbuf.p + n;
-  hipLaunchKernelGGL(lgicp::graph_degree_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d_bits, n, words, c_a);
-  const int hx_blocks = std::max(1, std::min((n + 3) / 4, 2048));
-  int n_rounds = 0;
-  for (;;) {  // every round lowers at least one value or ends the loop: at most n * n rounds
-    if (hipMemsetAsync(B.flags.p, 0, sizeof(int) * kRoundsPerCheck, st) != hipSuccess) return false;
-    for (int r = 0; r < kRoundsPerCheck; ++r) {
-      hipLaunchKernelGGL(lgicp::core_hindex_kernel, dim3(hx_blocks), dim3(256), lds_bytes, st, d_bits, n, words,
-                         c_a, c_b, B.flags.p + r);
-      std::swap(c_a, c_b);
+  unsigned long long* pl_cur = B.planes_a.p;
+  unsigned long long* pl_nxt = B.planes_b.p;
+  bool first_chunk = true;
+  std::vector<char> settled((size_t)P, 0);
+  int n_rounds = 0, n_alive = P;
+  int2* h_blk = reinterpret_cast<int2*>(B.h_up.p + tab_bytes);
+  while (n_alive > 0) {  // every round lowers at least one value of a pair or settles it
+    size_t nb = 0;
+    for (int p = 0; p < P; ++p)
+      if (!settled[p])
+        for (int v0 = 0; v0 < tab[p].n; v0 += lgicp::HX_VPB) h_blk[nb++] = make_int2(p, v0);
+    if (hipMemcpyAsync(B.blk.p, h_blk, sizeof(int2) * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(B.flags.p, 0, sizeof(int) * (size_t)P * lgicp::HX_ROUNDS, st) != hipSuccess)
+      return false;
+    if (first_chunk) {  // the degrees as planes
+      hipLaunchKernelGGL(lgicp::value_planes_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, B.table.p,
+                         B.blk.p, (int)nb, B.c.p, pl_cur);
+      first_chunk = false;
     }
-    n_rounds += kRoundsPerCheck;
-    int flags[kRoundsPerCheck];
+    for (int r = 0; r < lgicp::HX_ROUNDS; ++r) {
+      hipLaunchKernelGGL(lgicp::core_hindex_group_kernel, dim3((unsigned)nb), dim3(256), lds_bytes, st,
+                         B.table.p, B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r);
+      std::swap(pl_cur, pl_nxt);
+    }
+    n_rounds += lgicp::HX_ROUNDS;
+    int* h_flags = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(flags, B.flags.p, sizeof(flags), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(h_flags, B.flags.p, sizeof(int) * (size_t)P * lgicp::HX_ROUNDS, hipMemcpyDeviceToHost, st) !=
+            hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return false;
-    if (flags[kRoundsPerCheck - 1] == 0) break;  // the last round moved nothing: fixed point
-    if (n_rounds > 4 * n + 64) return false;
+    for (int p = 0; p < P; ++p)
+      if (!settled[p] && h_flags[p * lgicp::HX_ROUNDS + lgicp::HX_ROUNDS - 1] == 0) settled[p] = 1, --n_alive;
+    if (n_rounds > 4 * max_n + 64) return false;
   }
-  hipLaunchKernelGGL(lgicp::core_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c_a, n, B.K.p);
-  if (hipGetLastError() != hipSuccess) return false;
-  std::vector<int> K((size_t)n);
-  if (hipMemcpyAsync(K.data(), B.K.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+  unsigned short* h_c = reinterpret_cast<unsigned short*>(B.h_down.p);
+  if (hipMemcpyAsync(h_c, B.c.p, sizeof(unsigned short) * total_c, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     return false;
   const double ms_core = ms_since(t_0);
   const auto t_1 = std::chrono::steady_clock::now();
   // ---- orders (teaser::greedy_clique): starts by decreasing bound, ascending id among equals;
-  // candidates by decreasing bound, then decreasing id
-  std::vector<int> order((size_t)n), pref((size_t)n);
-  for (int i = 0; i < n; ++i) order[i] = pref[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return K[a] > K[b]; });
-  std::sort(pref.begin(), pref.end(), [&](int a, int b) { return K[a] != K[b] ? K[a] > K[b] : a > b; });
-  if (hipMemcpyAsync(B.pref.p, pref.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess)
+  // candidates by decreasing bound, then decreasing id.  Counting sorts over the bounds.
+  struct Search {
+    std::vector<int> K, order;
+    int mc = 0, at = 0, win = 1;
+    int best_v = -1, best_size = 0;
+    size_t best_loc = 0;
+    bool done = false;
+    int seg_first = 0, seg_count = 0;   // its starts in the current round
+    std::vector<int> window_pos;
+  };
+  std::vector<Search> S((size_t)P);
+  unsigned short* h_pref = reinterpret_cast<unsigned short*>(B.h_up.p + tab_bytes);
+  for (int p = 0; p < P; ++p) {
+    const int n = tab[p].n;
+    Search& s = S[p];
+    s.K.resize((size_t)n), s.order.resize((size_t)n);
+    int max_k = 0;
+    for (int v = 0; v < n; ++v) max_k = std::max(max_k, s.K[v] = (int)h_c[tab[p].c_off + v] + 1);
+    std::vector<int> first((size_t)max_k + 2, 0);  // first[k] = vertices with a larger bound
+    for (int v = 0; v < n; ++v) first[s.K[v]]++;
+    int run = 0;
+    for (int k = max_k; k >= 0; --k) {
+      const int c = first[k];
+      first[k] = run;
+      run += c;
+    }
+    std::vector<int> next = first;
+    for (int v = 0; v < n; ++v) s.order[next[s.K[v]]++] = v;
+    next = first;
+    unsigned short* pr = h_pref + tab[p].c_off;
+    for (int v = n - 1; v >= 0; --v) pr[next[s.K[v]]++] = (unsigned short)v;
+  }
+  if (hipMemcpyAsync(B.pref.p, h_pref, sizeof(unsigned short) * total_c, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)  // h_up is rewritten below
     return false;
-  // ---- windows of starts ------------------------------------------------------------------------
   const double ms_sort = ms_since(t_1);
   const auto t_2 = std::chrono::steady_clock::now();
-  int n_windows = 0, n_starts = 0;
-  std::vector<int> best, window, window_pos, sizes;
-  int mc = 0, at = 0, win = 1;
-  while (at < n) {
-    window.clear(), window_pos.clear();
-    int scan = at;
-    while (scan < n && (int)window.size() < win) {
-      const int v = order[scan++];
-      if (K[v] > mc) window.push_back(v), window_pos.push_back(scan);
-    }
-    if (window.empty()) break;
-    const int S = (int)window.size();
-    ++n_windows, n_starts += S;
-    sizes.assign((size_t)S, 0);
-    if (hipMemcpyAsync(B.starts.p, window.data(), sizeof(int) * (size_t)S, hipMemcpyHostToDevice, st) != hipSuccess)
-      return false;
-    hipLaunchKernelGGL(lgicp::clique_eligible_kernel, dim3((words + 255) / 256), dim3(256), 0, st, B.K.p, n,
-                       words, mc, B.elig.p);
-    hipLaunchKernelGGL(lgicp::clique_starts_kernel, dim3(S), dim3(64), 0, st, d_bits, n, words, B.pref.p,
-                       B.elig.p, B.starts.p, mc, B.sizes.p, (int*)nullptr);
-    if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(sizes.data(), B.sizes.p, sizeof(int) * (size_t)S, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      return false;
-    int improved = -1;
-    for (int k = 0; k < S; ++k)
-      if (sizes[k] > 0 && sizes[k] + 1 > mc) {
-        improved = k;
-        break;
+  // ---- windows of starts -------------------------------------------------------------------------
+  int n_windows = 0;
+  long long n_starts = 0, n_alone = 0;
+  std::vector<int2> starts;
+  for (int round = 0;; ++round) {
+    starts.clear();
+    const int parity = round & 1;
+    for (int p = 0; p < P; ++p) {
+      Search& s = S[p];
+      s.seg_first = (int)starts.size(), s.seg_count = 0;
+      if (s.done) continue;
+      const int n = tab[p].n;
+      s.window_pos.clear();
+      int scan = s.at;
+      while (scan < n && s.seg_count < s.win) {
+        const int v = s.order[scan++];
+        if (s.K[v] > s.mc) starts.push_back(make_int2(p, v)), s.window_pos.push_back(scan), ++s.seg_count;
       }
-    if (improved < 0) {
-      at = scan;
-      win = std::min(win * 16, kMaxWindow);
-      continue;
+      if (s.seg_count == 0) {
+        s.done = true;
+        continue;
+      }
+      s.at = scan;  // where the pair goes on when no start of the window improves
+      tab[p].mc = s.mc;
+      tab[p].list_off = (int)(list_base[p] + (size_t)parity * (lgicp::CLQ_SLOTS + 1) * tab[p].n_pad);
     }
-    // the serial rule: this start raises the size; the starts after it see the new size.  Its
-    // members come from running it once more on its own (improvements are rare, and the windows
-    // need not keep a member list per start this way).
-    best.resize((size_t)sizes[improved]);
-    hipLaunchKernelGGL(lgicp::clique_starts_kernel, dim3(1), dim3(64), 0, st, d_bits, n, words, B.pref.p,
-                       B.elig.p, B.starts.p + improved, mc, B.sizes.p, B.lists.p);
+    const size_t n_s = starts.size();
+    if (n_s == 0) break;
+    ++n_windows, n_starts += (long long)n_s;
+    if (B.starts.reserve(n_s) != hipSuccess || B.out.reserve(2 * n_s) != hipSuccess ||
+        !B.h_up.reserve(tab_bytes + sizeof(int2) * n_s) || !B.h_down.reserve(sizeof(int) * 2 * n_s))
+      return false;
+    std::memcpy(B.h_up.p + tab_bytes, starts.data(), sizeof(int2) * n_s);
+    if (!upload_table() ||
+        hipMemcpyAsync(B.starts.p, B.h_up.p + tab_bytes, sizeof(int2) * n_s, hipMemcpyHostToDevice, st) != hipSuccess)
+      return false;
+    hipLaunchKernelGGL(lgicp::clique_eligible_group_kernel, dim3((max_words + 255) / 256, P), dim3(256), 0, st,
+                       B.table.p, B.c.p, B.elig.p, B.tickets.p);
+    hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<false>, dim3((unsigned)n_s), dim3(64), 0, st, B.table.p,
+                       B.pref.p, B.elig.p, B.starts.p, B.out.p, B.lists.p, B.tickets.p);
+    int* h_out = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(best.data(), B.lists.p, sizeof(int) * best.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(h_out, B.out.p, sizeof(int) * 2 * n_s, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return false;
-    best.push_back(window[improved]);
-    mc = (int)best.size();
-    at = window_pos[improved];
-    win = std::min(std::max(win, 4) * 16, kMaxWindow);
+    std::vector<int2> alone;  // improving starts whose members were not kept: run once more
+    for (int p = 0; p < P; ++p) {
+      Search& s = S[p];
+      if (s.done || s.seg_count == 0) continue;
+      int improved = -1;
+      for (int k = 0; k < s.seg_count; ++k) {
+        const int sz = h_out[2 * (s.seg_first + k)];
+        if (sz > 0 && sz + 1 > s.mc) {
+          improved = k;
+          break;
+        }
+      }
+      if (improved < 0) {
+        s.win = std::min(s.win * 16, kMaxWindow);
+        continue;
+      }
+      // the serial rule: this start raises the size; the starts after it see the new size
+      const int at_s = s.seg_first + improved;
+      const int ticket = h_out[2 * at_s + 1];
+      s.best_size = h_out[2 * at_s];
+      s.best_v = starts[at_s].y;
+      if (ticket >= 0) {
+        s.best_loc = (size_t)tab[p].list_off + (size_t)ticket * tab[p].n_pad;
+      } else {
+        s.best_loc = (size_t)tab[p].list_off + (size_t)lgicp::CLQ_SLOTS * tab[p].n_pad;
+        alone.push_back(starts[at_s]);
+      }
+      s.mc = s.best_size + 1;
+      s.at = s.window_pos[improved];
+      s.win = std::min(std::max(s.win, 4) * 16, kMaxWindow);
+    }
+    if (!alone.empty()) {
+      // same table (old mc, old eligibility) as the window they come from
+      n_alone += (long long)alone.size();
+      std::memcpy(B.h_up.p + tab_bytes, alone.data(), sizeof(int2) * alone.size());
+      if (hipMemcpyAsync(B.starts.p, B.h_up.p + tab_bytes, sizeof(int2) * alone.size(), hipMemcpyHostToDevice, st) !=
+          hipSuccess)
+        return false;
+      hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<true>, dim3((unsigned)alone.size()), dim3(64), 0, st,
+                         B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.lists.p, B.tickets.p);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
+    }
+  }
+  // ---- the members of every pair's best start ----------------------------------------------------
+  size_t total_best = 0;
+  for (int p = 0; p < P; ++p) total_best += (size_t)S[p].best_size;
+  if (!B.h_down.reserve(sizeof(unsigned short) * (total_best + 1))) return false;
+  unsigned short* h_l = reinterpret_cast<unsigned short*>(B.h_down.p);
+  size_t o = 0;
+  for (int p = 0; p < P; ++p) {
+    if (S[p].best_size > 0 &&
+        hipMemcpyAsync(h_l + o, B.lists.p + S[p].best_loc, sizeof(unsigned short) * (size_t)S[p].best_size,
+                       hipMemcpyDeviceToHost, st) != hipSuccess)
+      return false;
+    o += (size_t)S[p].best_size;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return false;
+  o = 0;
+  for (int p = 0; p < P; ++p) {
+    std::vector<int>& best = cliques[ids[p]];
+    for (int i = 0; i < S[p].best_size; ++i) best.push_back((int)h_l[o + i]);
+    o += (size_t)S[p].best_size;
+    if (S[p].best_v >= 0) best.push_back(S[p].best_v);
+    std::sort(best.begin(), best.end());
   }
   if (trace)
-    std::fprintf(stderr, "[lgicp] clique search on the device: %d vertices, core numbers %.2f ms (%d rounds), "
-                 "orders %.2f ms, %d windows / %d starts %.2f ms, clique %zu\n", n, ms_core, n_rounds, ms_sort, n_windows,
-                 n_starts, ms_since(t_2), best.size());
-  std::sort(best.begin(), best.end());
-  *clique = std::move(best);
+    std::fprintf(stderr, "[lgicp] clique search on the device: %d graphs (largest %d vertices), core numbers %.2f ms "
+                 "(%d rounds), orders %.2f ms, %d windows / %lld starts (%lld run alone) %.2f ms\n", P, max_n, ms_core,
+                 n_rounds, ms_sort, n_windows, n_starts, n_alone, ms_since(t_2));
   return true;
+}
+
+bool greedy_clique_device(int device, hipStream_t st, const unsigned long long* d_bits, int n, int words,
+                          std::vector<int>* clique) {
+  const CliqueGraph g{d_bits, n, words};
+  return greedy_clique_group(device, st, &g, 1, clique);
 }
 
 }  // namespace lgicp_detail
