@@ -274,8 +274,9 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __
 // ---------------------------------------------------------------------------------------------
 // GNC-TLS rotation over the pairwise differences of a clique of m matches (the host loop is
 // teaser::gnc_rotation): with m in the thousands the m (m - 1) / 2 differences are millions and
-// every one of the up to 100 iterations sums over all of them.  Workgroup (bx, i) owns the
-// differences (i, j), j = bx * 256 + lane, j > i, recomputed from the m points each time.  One
+// every one of the up to 100 iterations sums over all of them.  Workgroup (bx, by) owns the
+// differences (i, j), j = bx * 256 + lane, i in the by-th block of GNC_ROWS rows, j > i, recomputed
+// from the m points each time (the row's point is read with wave-uniform addresses).  One
 // launch does everything an iteration needs from a given rotation: residuals, their maximum, the
 // cost under the old weights, the new weights (kept in an m x m array) and the correlation
 // matrix under the new weights for the next rotation.  Each workgroup leaves 11 partial values;
@@ -299,6 +300,7 @@ struct GncJobDev {
 };
 constexpr int GNC_THREADS = 256;
 constexpr int GNC_VALUES = 11;  // H (9), cost, max residual
+constexpr int GNC_ROWS = 32;    // rows of the difference matrix per workgroup
 
 __global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __restrict__ cs_all,
                                                                const double* __restrict__ cd_all,
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __r
   __shared__ double sh[GNC_THREADS / 64][GNC_VALUES];
   const GncJobDev* J = jobs + blockIdx.z;
   const int m = J->m, gx = J->gx;
-  const int i = blockIdx.y;
-  if (i >= m || (int)blockIdx.x >= gx) return;  // the grid spans the largest clique of the group
+  const int i_lo = blockIdx.y * GNC_ROWS;
+  if (i_lo >= m || (int)blockIdx.x >= gx) return;  // the grid spans the largest clique of the group
   const GncStep& k = J->k;
   const double* cs = cs_all + 3 * (size_t)J->pt_off;
   const double* cd = cd_all + 3 * (size_t)J->pt_off;
@@ -318,10 +320,15 @@ __global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __r
   double v[GNC_VALUES];
 #pragma unroll
   for (int q = 0; q < GNC_VALUES; ++q) v[q] = 0.0;
-  if (j > i && j < m) {
+  const int jj = j < m ? j : 0;
+  const double sj[3] = {cs[3 * jj], cs[3 * jj + 1], cs[3 * jj + 2]};
+  const double dj[3] = {cd[3 * jj], cd[3 * jj + 1], cd[3 * jj + 2]};
+  const int i_hi = min(i_lo + GNC_ROWS, m);
+  for (int i = i_lo; i < i_hi; ++i) {
+    if (!(j > i && j < m)) continue;
     double x[3], y[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) x[a] = cs[3 * j + a] - cs[3 * i + a], y[a] = cd[3 * j + a] - cd[3 * i + a];
+    for (int a = 0; a < 3; ++a) x[a] = sj[a] - cs[3 * i + a], y[a] = dj[a] - cd[3 * i + a];
     double res = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -338,9 +345,9 @@ __global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __r
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) v[a * 3 + b] = x[a] * wn * y[b];
-    v[9] = wo * res;
-    v[10] = res;
+      for (int b = 0; b < 3; ++b) v[a * 3 + b] += x[a] * wn * y[b];
+    v[9] += wo * res;
+    v[10] = fmax(v[10], res);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(GNC_THREADS) void gnc_fold_kernel(const double* __r
   __shared__ double sh[GNC_THREADS][GNC_VALUES];
   const GncJobDev* J = jobs + blockIdx.x;
   const double* partial = partial_all + (size_t)J->part_off * GNC_VALUES;
-  const int n = J->gx * J->m;
+  const int n = J->gx * ((J->m + GNC_ROWS - 1) / GNC_ROWS);
   double v[GNC_VALUES];
 #pragma unroll
   for (int q = 0; q < GNC_VALUES; ++q) v[q] = 0.0;
@@ -615,7 +622,7 @@ static bool clique_rotation_group(int device, hipStream_t st, RotJob* jobs, int 
       for (int i = 0; i < 9; ++i) s.d.k.R[i] = jobs[last].R[i] = (i % 4 == 0) ? 1.0 : 0.0;
       s.d.k.init = 1;
       S.push_back(s);
-      n_w += w_m, n_pt += (size_t)m, n_part += (size_t)s.d.gx * m;
+      n_w += w_m, n_pt += (size_t)m, n_part += (size_t)s.d.gx * ((m + lgicp::GNC_ROWS - 1) / lgicp::GNC_ROWS);
       max_m = std::max(max_m, m), max_gx = std::max(max_gx, s.d.gx);
       ++last;
     }
@@ -655,7 +662,8 @@ static bool clique_rotation_group(int device, hipStream_t st, RotJob* jobs, int 
       const double* h_out = reinterpret_cast<const double*>(dev.h_down.p);
       if (hipMemcpyAsync(dev.table.p, h_tab, sizeof(GncJobDev) * active.size(), hipMemcpyHostToDevice, st) != hipSuccess)
         return false;
-      hipLaunchKernelGGL(lgicp::gnc_step_kernel, dim3(gg, gm, (unsigned)active.size()), dim3(lgicp::GNC_THREADS), 0,
+      hipLaunchKernelGGL(lgicp::gnc_step_kernel, dim3(gg, (gm + lgicp::GNC_ROWS - 1) / lgicp::GNC_ROWS, (unsigned)active.size()),
+                         dim3(lgicp::GNC_THREADS), 0,
                          st, dev.cs.p, dev.cd.p, dev.table.p, dev.w.p, dev.partial.p);
       hipLaunchKernelGGL(lgicp::gnc_fold_kernel, dim3((unsigned)active.size()), dim3(lgicp::GNC_THREADS), 0, st,
                          dev.partial.p, dev.table.p, dev.out.p);

@@ -48,8 +48,8 @@ struct GraphDev {
   int c_off;     // first element of the pair's per-vertex arrays
   int w_off;     // first word of its eligibility set
   int mc;        // best clique size so far
-  int list_off;  // first element of the member-list slots this round's starts may fill
-  int n_pad;     // elements per slot
+  int list_off;  // first word of the member-set slots this round's starts may fill
+  int n_pad;     // elements of the per-vertex arrays (n rounded up to a multiple of 8, plus 8)
   int nbits;     // bits of a per-vertex value (values < n <= 2^nbits)
   int stride;    // words per bit plane (words rounded up to even)
   int pl_off;    // first word of the pair's bit planes
@@ -59,8 +59,7 @@ constexpr int HX_ROUNDS = 8;        // H-operator rounds between two looks at th
 constexpr int HX_VPW = 16;          // vertices per wave and round
 constexpr int HX_VPB = 4 * HX_VPW;  // per workgroup of four waves: the 64 vertices of one bit-set word
 constexpr int CLQ_MAX_WORDS = 1024;  // 65536 matches
-constexpr int CLQ_SLOTS = 16;        // member lists a pair can keep per round (+1 for a start run alone)
-constexpr int CLQ_LIST_CAP = 4096;   // members a start keeps in LDS
+constexpr int CLQ_SLOTS = 16;        // member sets a pair can keep per round (+1 for a start run alone)
 
 // degree of every vertex: one wave per row of the bit matrix
 __global__ __launch_bounds__(256) void graph_degree_kernel(const unsigned long long* __restrict__ bits, int n,
@@ -211,28 +210,28 @@ __global__ __launch_bounds__(256) void clique_eligible_group_kernel(const GraphD
 }
 
 // One wave per start.  starts[s] = (pair, start vertex); out[2 s] = members found besides the start
-// vertex (0: cannot beat the pair's mc), out[2 s + 1] = the list slot that holds them in the order
-// they joined (-1: none; the host then runs the start once more on its own with kDirect, which
-// writes the members straight into the pair's extra slot).
-template <bool kDirect>
+// vertex (0: cannot beat the pair's mc), out[2 s + 1] = the slot that holds them as a bit set
+// (-1: none; the host then runs the start once more on its own with kAlone, which always writes
+// its members, into the pair's extra slot).
+template <bool kAlone>
 __global__ __launch_bounds__(64) void clique_starts_group_kernel(
     const GraphDev* __restrict__ graphs, const unsigned short* __restrict__ pref_all,
     const unsigned long long* __restrict__ elig_all, const int2* __restrict__ starts,
-    int* __restrict__ out, unsigned short* __restrict__ lists, int* __restrict__ tickets) {
+    int* __restrict__ out, unsigned long long* __restrict__ sets, int* __restrict__ tickets) {
   __shared__ unsigned long long cand[CLQ_MAX_WORDS];
-  __shared__ unsigned short lst[kDirect ? 8 : CLQ_LIST_CAP];
+  __shared__ unsigned long long memb[CLQ_MAX_WORDS];
   const int s = blockIdx.x, lane = threadIdx.x;
   const int2 sv = starts[s];
   const GraphDev G = graphs[sv.x];
   const int v = sv.y, n = G.n, words = G.words, mc = G.mc;
   const unsigned short* pref = pref_all + G.c_off;
   const unsigned long long* elig = elig_all + G.w_off;
-  unsigned short* const direct = lists + (size_t)G.list_off + (size_t)CLQ_SLOTS * G.n_pad;
   const unsigned long long* rv = G.bits + (size_t)v * words;
   int np = 0;
   for (int w = lane; w < words; w += 64) {
     const unsigned long long x = rv[w] & elig[w];
     cand[w] = x;
+    memb[w] = 0;
     np += __builtin_popcountll(x);
   }
 #pragma unroll
@@ -254,12 +253,7 @@ __global__ __launch_bounds__(64) void clique_starts_group_kernel(
       const int first = __builtin_ctzll(m);
       const int pick = __builtin_amdgcn_readlane(u, first);
       at += first + 1;
-      if (lane == 0) {
-        if (kDirect)
-          direct[size] = (unsigned short)pick;
-        else if (size < CLQ_LIST_CAP)
-          lst[size] = (unsigned short)pick;
-      }
+      if (lane == 0) memb[pick >> 6] |= 1ull << (pick & 63);
       ++size;
       const unsigned long long* r = G.bits + (size_t)pick * words;
       int left = 0;
@@ -283,21 +277,19 @@ __global__ __launch_bounds__(64) void clique_starts_group_kernel(
   }
   int ticket = -1;
   if (size > 0 && size + 1 > mc) {
-    if (kDirect) {
-      ticket = CLQ_SLOTS;
-    } else if (size <= CLQ_LIST_CAP) {
-      // The host wants the members of the pair's first improving start in window order only: a
-      // start keeps its list when no start before it has improved so far (the first one always
-      // passes this test; the others that do are few, a sequence of running minima).
-      int t = CLQ_SLOTS;
+    // The host wants the members of the pair's first improving start in window order only: a
+    // start keeps its set when no start before it has improved so far (the first one always
+    // passes this test; the others that do are few, a sequence of running minima).
+    int t = CLQ_SLOTS;
+    if (!kAlone) {
       if (lane == 0 && atomicMin(&tickets[2 * sv.x + 1], s) > s) t = atomicAdd(&tickets[2 * sv.x], 1);
       t = __builtin_amdgcn_readfirstlane(t);
-      if (t < CLQ_SLOTS) {
-        __syncthreads();  // lane 0's list entries
-        unsigned short* dst = lists + (size_t)G.list_off + (size_t)t * G.n_pad;
-        for (int i = lane; i < size; i += 64) dst[i] = lst[i];
-        ticket = t;
-      }
+    }
+    if (kAlone || t < CLQ_SLOTS) {
+      __syncthreads();  // lane 0's member bits
+      unsigned long long* dst = sets + (size_t)G.list_off + (size_t)t * G.stride;
+      for (int w = lane; w < words; w += 64) dst[w] = memb[w];
+      ticket = t;
     }
   }
   if (lane == 0) {
@@ -335,8 +327,8 @@ struct PinBuf {  // grow-only pinned host array
 // buffers of the clique search, one set per host thread and device, reused from group to group
 struct CliqueGroupDev {
   int device = -1;
-  DevBuf<unsigned short> c, pref, lists;
-  DevBuf<unsigned long long> elig, planes_a, planes_b;
+  DevBuf<unsigned short> c, pref;
+  DevBuf<unsigned long long> elig, planes_a, planes_b, sets;
   DevBuf<lgicp::GraphDev> table;
   DevBuf<int2> blk, starts;
   DevBuf<int> flags, out, tickets;
@@ -346,7 +338,7 @@ struct CliqueGroupDev {
       int cur = -1;
       (void)hipGetDevice(&cur);
       if (cur != device) (void)hipSetDevice(device);
-      c.release(), pref.release(), lists.release(), elig.release(), table.release();
+      c.release(), pref.release(), sets.release(), elig.release(), table.release();
       planes_a.release(), planes_b.release();
       blk.release(), starts.release(), flags.release(), out.release(), tickets.release();
       h_up.release(), h_down.release();
@@ -410,16 +402,16 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     total_pl += (size_t)t.nbits * t.stride;
     max_planes = std::max(max_planes, (size_t)t.nbits * t.stride);
     list_base[p] = total_l;
+    total_l += (size_t)2 * (lgicp::CLQ_SLOTS + 1) * t.stride;
     total_c += (size_t)t.n_pad;
     total_w += (size_t)g.words;
-    total_l += (size_t)2 * (lgicp::CLQ_SLOTS + 1) * t.n_pad;
     total_blk += (size_t)(g.n + lgicp::HX_VPB - 1) / lgicp::HX_VPB;
     max_n = std::max(max_n, g.n), max_words = std::max(max_words, g.words);
   }
   if (total_l > (size_t)INT_MAX || total_c > (size_t)INT_MAX || total_pl > (size_t)INT_MAX) return false;
   if (B.c.reserve(total_c) != hipSuccess || B.planes_a.reserve(total_pl) != hipSuccess ||
       B.planes_b.reserve(total_pl) != hipSuccess ||
-      B.pref.reserve(total_c) != hipSuccess || B.lists.reserve(total_l) != hipSuccess ||
+      B.pref.reserve(total_c) != hipSuccess || B.sets.reserve(total_l) != hipSuccess ||
       B.elig.reserve(total_w) != hipSuccess || B.table.reserve((size_t)P) != hipSuccess ||
       B.blk.reserve(total_blk) != hipSuccess || B.flags.reserve((size_t)P * lgicp::HX_ROUNDS) != hipSuccess ||
       B.tickets.reserve((size_t)2 * P) != hipSuccess)
@@ -552,7 +544,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       }
       s.at = scan;  // where the pair goes on when no start of the window improves
       tab[p].mc = s.mc;
-      tab[p].list_off = (int)(list_base[p] + (size_t)parity * (lgicp::CLQ_SLOTS + 1) * tab[p].n_pad);
+      tab[p].list_off = (int)(list_base[p] + (size_t)parity * (lgicp::CLQ_SLOTS + 1) * tab[p].stride);
     }
     const size_t n_s = starts.size();
     if (n_s == 0) break;
@@ -567,7 +559,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     hipLaunchKernelGGL(lgicp::clique_eligible_group_kernel, dim3((max_words + 255) / 256, P), dim3(256), 0, st,
                        B.table.p, B.c.p, B.elig.p, B.tickets.p);
     hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<false>, dim3((unsigned)n_s), dim3(64), 0, st, B.table.p,
-                       B.pref.p, B.elig.p, B.starts.p, B.out.p, B.lists.p, B.tickets.p);
+                       B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p);
     int* h_out = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(h_out, B.out.p, sizeof(int) * 2 * n_s, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -595,14 +587,14 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       s.best_size = h_out[2 * at_s];
       s.best_v = starts[at_s].y;
       if (ticket >= 0) {
-        s.best_loc = (size_t)tab[p].list_off + (size_t)ticket * tab[p].n_pad;
+        s.best_loc = (size_t)tab[p].list_off + (size_t)ticket * tab[p].stride;
       } else {
-        s.best_loc = (size_t)tab[p].list_off + (size_t)lgicp::CLQ_SLOTS * tab[p].n_pad;
+        s.best_loc = (size_t)tab[p].list_off + (size_t)lgicp::CLQ_SLOTS * tab[p].stride;
         alone.push_back(starts[at_s]);
       }
       s.mc = s.best_size + 1;
       s.at = s.window_pos[improved];
-      s.win = std::min(std::max(s.win, 4) * 16, kMaxWindow);
+      s.win = std::min(std::max(s.win, 64), kMaxWindow);  // improvements come in runs: do not grow yet
     }
     if (!alone.empty()) {
       // same table (old mc, old eligibility) as the window they come from
@@ -612,29 +604,32 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
           hipSuccess)
         return false;
       hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<true>, dim3((unsigned)alone.size()), dim3(64), 0, st,
-                         B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.lists.p, B.tickets.p);
+                         B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
     }
   }
   // ---- the members of every pair's best start ----------------------------------------------------
   size_t total_best = 0;
-  for (int p = 0; p < P; ++p) total_best += (size_t)S[p].best_size;
-  if (!B.h_down.reserve(sizeof(unsigned short) * (total_best + 1))) return false;
-  unsigned short* h_l = reinterpret_cast<unsigned short*>(B.h_down.p);
+  for (int p = 0; p < P; ++p) total_best += (size_t)tab[p].words;
+  if (!B.h_down.reserve(sizeof(unsigned long long) * (total_best + 1))) return false;
+  unsigned long long* h_l = reinterpret_cast<unsigned long long*>(B.h_down.p);
   size_t o = 0;
   for (int p = 0; p < P; ++p) {
     if (S[p].best_size > 0 &&
-        hipMemcpyAsync(h_l + o, B.lists.p + S[p].best_loc, sizeof(unsigned short) * (size_t)S[p].best_size,
+        hipMemcpyAsync(h_l + o, B.sets.p + S[p].best_loc, sizeof(unsigned long long) * (size_t)tab[p].words,
                        hipMemcpyDeviceToHost, st) != hipSuccess)
       return false;
-    o += (size_t)S[p].best_size;
+    o += (size_t)tab[p].words;
   }
   if (hipStreamSynchronize(st) != hipSuccess) return false;
   o = 0;
   for (int p = 0; p < P; ++p) {
     std::vector<int>& best = cliques[ids[p]];
-    for (int i = 0; i < S[p].best_size; ++i) best.push_back((int)h_l[o + i]);
-    o += (size_t)S[p].best_size;
+    if (S[p].best_size > 0)
+      for (int w = 0; w < tab[p].words; ++w)
+        for (unsigned long long m = h_l[o + w]; m; m &= m - 1) best.push_back((w << 6) + __builtin_ctzll(m));
+    o += (size_t)tab[p].words;
+    if ((int)best.size() != S[p].best_size) return false;  // the set and the size the start reported disagree
     if (S[p].best_v >= 0) best.push_back(S[p].best_v);
     std::sort(best.begin(), best.end());
   }
