@@ -155,25 +155,34 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
       for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
       return c;
     };
+    // H lies in [lo, hi].  A probe p with count c = count_ge(p) narrows both ends: count_ge never
+    // grows with h, so c >= p means p <= H <= c, and c < p means c <= H <= p - 1 (count_ge(c) >=
+    // count_ge(p) = c).  The new value usually lies just below the old one (the counts jump where
+    // many neighbours share a value), so the probes gallop down from the top, then bisect.
     int h = cv;
-    if (cv > 0 && count_ge(cv) < cv) {
-      // the new value lies below cv, usually just below: gallop down from the top, then bisect
-      int hi = cv - 1, lo = 0, step = 1;  // count_ge(lo) >= lo holds (lo = 0 trivially)
-      for (;;) {
-        const int probe = hi - step + 1;
-        if (probe <= 0) break;
-        if (count_ge(probe) >= probe) {
-          lo = probe;
-          break;
+    if (cv > 0) {
+      const int c0 = count_ge(cv);
+      if (c0 < cv) {
+        int lo = c0, hi = cv - 1, step = 1;
+        auto probe_at = [&](int probe) {
+          const int c = count_ge(probe);
+          if (c >= probe) {
+            lo = probe;
+            hi = min(hi, c);
+            return true;
+          }
+          hi = probe - 1;
+          lo = max(lo, c);
+          return false;
+        };
+        while (lo < hi) {
+          const int probe = hi - step + 1;
+          if (probe <= lo || probe_at(probe)) break;
+          step <<= 1;
         }
-        hi = probe - 1;
-        step <<= 1;
+        while (lo < hi) probe_at((lo + hi + 1) >> 1);
+        h = lo;
       }
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (count_ge(mid) >= mid) lo = mid; else hi = mid - 1;
-      }
-      h = lo;
     }
     if (lane == 0) {
       res[wave * HX_VPW + q] = (unsigned short)h;
@@ -217,9 +226,12 @@ template <bool kAlone>
 __global__ __launch_bounds__(64) void clique_starts_group_kernel(
     const GraphDev* __restrict__ graphs, const unsigned short* __restrict__ pref_all,
     const unsigned long long* __restrict__ elig_all, const int2* __restrict__ starts,
-    int* __restrict__ out, unsigned long long* __restrict__ sets, int* __restrict__ tickets) {
-  __shared__ unsigned long long cand[CLQ_MAX_WORDS];
-  __shared__ unsigned long long memb[CLQ_MAX_WORDS];
+    int* __restrict__ out, unsigned long long* __restrict__ sets, int* __restrict__ tickets, int lds_words) {
+  // dynamic LDS: candidate set and member set, `lds_words` words each (the widest graph of the
+  // group: the fewer bytes a start holds, the more starts a CU runs side by side)
+  extern __shared__ unsigned long long clq_lds[];
+  unsigned long long* const cand = clq_lds;
+  unsigned long long* const memb = clq_lds + lds_words;
   const int s = blockIdx.x, lane = threadIdx.x;
   const int2 sv = starts[s];
   const GraphDev G = graphs[sv.x];
@@ -523,6 +535,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   // ---- windows of starts -------------------------------------------------------------------------
   int n_windows = 0;
   long long n_starts = 0, n_alone = 0;
+  const size_t clq_lds_bytes = sizeof(unsigned long long) * 2 * (size_t)max_words;
   std::vector<int2> starts;
   for (int round = 0;; ++round) {
     starts.clear();
@@ -558,8 +571,8 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       return false;
     hipLaunchKernelGGL(lgicp::clique_eligible_group_kernel, dim3((max_words + 255) / 256, P), dim3(256), 0, st,
                        B.table.p, B.c.p, B.elig.p, B.tickets.p);
-    hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<false>, dim3((unsigned)n_s), dim3(64), 0, st, B.table.p,
-                       B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p);
+    hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<false>, dim3((unsigned)n_s), dim3(64), clq_lds_bytes, st,
+                       B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p, max_words);
     int* h_out = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(h_out, B.out.p, sizeof(int) * 2 * n_s, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -603,8 +616,9 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       if (hipMemcpyAsync(B.starts.p, B.h_up.p + tab_bytes, sizeof(int2) * alone.size(), hipMemcpyHostToDevice, st) !=
           hipSuccess)
         return false;
-      hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<true>, dim3((unsigned)alone.size()), dim3(64), 0, st,
-                         B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p);
+      hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<true>, dim3((unsigned)alone.size()), dim3(64),
+                         clq_lds_bytes, st, B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p,
+                         max_words);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
     }
   }
