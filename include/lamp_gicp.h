@@ -166,6 +166,14 @@ typedef struct lgicp_stats {
   uint64_t cycle_exits;         /* pairs of the last submit that left the outer loop because their
                                    transformation revisited one of its last 16 values (an exit the
                                    reference does not have; reserved[5] bit 1 switches it off) */
+  /* TEASERPP initialisation, last submit: the two kernels its time goes to, hipEvent durations
+     summed over their launches, and the bytes of consistency-graph rows they had to read */
+  double clique_ms;             /* clique_starts_group_kernel */
+  double clique_row_bytes;      /* one row per start and per clique member a start tried */
+  uint64_t clique_launches;
+  uint64_t hindex_launches;
+  double hindex_ms;             /* core_hindex_group_kernel */
+  double hindex_matrix_bytes;   /* the bit matrix of every graph still iterating, once per round */
 } lgicp_stats;
 
 typedef struct lgicp_ctx lgicp_ctx;

@@ -65,7 +65,10 @@ class Stats(C.Structure):
                 ("total_ms", C.c_double), ("last_nn_kernel_ms", C.c_double),
                 ("last_nn_evals_per_launch", C.c_double), ("nn_executed_evals", C.c_double),
                 ("reduce_points", C.c_double), ("reduce_inliers", C.c_double),
-                ("reduce_launches", C.c_uint64), ("cycle_exits", C.c_uint64)]
+                ("reduce_launches", C.c_uint64), ("cycle_exits", C.c_uint64),
+                ("clique_ms", C.c_double), ("clique_row_bytes", C.c_double),
+                ("clique_launches", C.c_uint64), ("hindex_launches", C.c_uint64),
+                ("hindex_ms", C.c_double), ("hindex_matrix_bytes", C.c_double)]
 
 
 class LgicpError(RuntimeError):

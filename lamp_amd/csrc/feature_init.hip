@@ -810,7 +810,7 @@ void teaser_prepare_collect(TeaserJob* job) {
 // error metrics are host work spread over threads.  T_out[i] is the guess unless the TEASER++
 // transform scores at least as well over the matches.
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
-                        float (*T_out)[16], int* used, int* n_clique) {
+                        float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times) {
   namespace tz = lgicp::teaser;
   for (int i = 0; i < count; ++i) {
     std::memcpy(T_out[i], guesses[i], sizeof(float) * 16);
@@ -831,7 +831,7 @@ int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* con
       else
         on_host.push_back(i);
     }
-    if (on_device && !greedy_clique_group(ctx->cfg.device, st, graphs.data(), count, cliques.data()))
+    if (on_device && !greedy_clique_group(ctx->cfg.device, st, graphs.data(), count, cliques.data(), times))
       return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: clique search over %d graphs (up to %d matches) "
                   "failed on the device (%s)", on_device, largest, hipGetErrorString(hipGetLastError()));
     // graphs the device path does not take (or reserved[4] = -1): the host search, pairs side by

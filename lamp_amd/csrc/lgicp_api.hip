@@ -529,7 +529,7 @@ void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t
 int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vector<CloudDev>& h_clouds,
                              const lgicp_candidate* cand, lgicp_result* out,
                              std::vector<PairDev>& h_pairs, std::vector<PairState>& h_state,
-                             std::vector<char>& init_rejected) {
+                             std::vector<char>& init_rejected, lgicp_stats& stats) {
   const lgicp_config& cfg = ctx->cfg;
   const int n_pairs = (int)bp.pairs.size();
   std::map<int, std::shared_ptr<CloudFeatures>> feat_ptr;
@@ -561,7 +561,7 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     // for one pair as for sixty-four).  Largest pairs first, so that the pairs of a group are of
     // similar size and the buffers of the slots are sized once.
     const bool trace = std::getenv("LGICP_TRACE") != nullptr;  // diagnostics on stderr
-    constexpr int kGroup = 64;
+    constexpr int kGroup = 128;
     constexpr size_t kGroupBytes = 6ull << 30;  // bit matrices of a group
     std::vector<std::shared_ptr<TeaserJob>>& slots = ctx->teaser_slots;
     while ((int)slots.size() < kGroup) slots.push_back(std::make_shared<TeaserJob>());
@@ -592,7 +592,12 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
       const auto t_b = std::chrono::steady_clock::now();
       float T0[kGroup][16];
       int used[kGroup], nc[kGroup];
-      const int rc = teaser_finish_group(ctx, jobs, guesses, g, T0, used, nc);
+      CliqueTimes ct;
+      const int rc = teaser_finish_group(ctx, jobs, guesses, g, T0, used, nc, &ct);
+      stats.clique_ms += ct.starts_ms, stats.clique_row_bytes += ct.starts_row_bytes;
+      stats.clique_launches += ct.starts_launches;
+      stats.hindex_ms += ct.hindex_ms, stats.hindex_matrix_bytes += ct.hindex_matrix_bytes;
+      stats.hindex_launches += ct.hindex_launches;
       if (rc != LGICP_OK) return rc;
       for (int j = 0; j < g; ++j) {
         const int p = group_pair[j];
@@ -950,7 +955,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   std::vector<char> init_rejected((size_t)n_pairs, 0);
   if (!explicit_guess &&
       (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP)) {
-    const int rc = initialise_from_features(ctx, bp, h_clouds, cand, out, h_pairs, h_state, init_rejected);
+    const int rc = initialise_from_features(ctx, bp, h_clouds, cand, out, h_pairs, h_state, init_rejected, W->stats);
     if (rc != LGICP_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDev) * n_pairs,
                                 hipMemcpyHostToDevice, st));
@@ -1226,6 +1231,10 @@ void merge_stats(lgicp_stats& into, const lgicp_stats& d) {
   into.reduce_points += d.reduce_points, into.reduce_inliers += d.reduce_inliers;
   into.reduce_launches += d.reduce_launches;
   into.cycle_exits += d.cycle_exits;
+  into.clique_ms += d.clique_ms, into.clique_row_bytes += d.clique_row_bytes;
+  into.clique_launches += d.clique_launches;
+  into.hindex_ms += d.hindex_ms, into.hindex_matrix_bytes += d.hindex_matrix_bytes;
+  into.hindex_launches += d.hindex_launches;
   if (d.last_nn_evals_per_launch > 0) {
     into.last_nn_kernel_ms = d.last_nn_kernel_ms;
     into.last_nn_evals_per_launch = d.last_nn_evals_per_launch;
@@ -1237,6 +1246,8 @@ void reset_submit_stats(lgicp_stats& s) {
   s.nn_executed_evals = s.reduce_points = s.reduce_inliers = 0;
   s.reduce_launches = 0;
   s.cycle_exits = 0;
+  s.clique_ms = s.clique_row_bytes = s.hindex_ms = s.hindex_matrix_bytes = 0;
+  s.clique_launches = s.hindex_launches = 0;
 }
 
 }  // namespace

@@ -335,8 +335,12 @@ struct CliqueGraph {
   const unsigned long long* d_bits;
   int n, words;
 };
+struct CliqueTimes {  // hipEvent durations and algorithmic bytes of the two kernels, accumulated
+  double starts_ms = 0, starts_row_bytes = 0, hindex_ms = 0, hindex_matrix_bytes = 0;
+  uint64_t starts_launches = 0, hindex_launches = 0;
+};
 bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* graphs, int count,
-                         std::vector<int>* cliques);
+                         std::vector<int>* cliques, CliqueTimes* times = nullptr);
 int clique_device_max_vertices();
 // first half: enqueues matcher and consistency graph of one pair on the context's stream and
 // returns; teaser_prepare_collect (after the stream has been synchronised) moves the matched
@@ -345,7 +349,7 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
                           TeaserJob* job);
 void teaser_prepare_collect(TeaserJob* job);
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
-                        float (*T_out)[16], int* used, int* n_clique);
+                        float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times = nullptr);
 
 // device address of the static scratch array behind lgicp_nn_search_static, looked up once per
 // device; `device` must be the current device

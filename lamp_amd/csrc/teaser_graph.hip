@@ -226,7 +226,8 @@ template <bool kAlone>
 __global__ __launch_bounds__(64) void clique_starts_group_kernel(
     const GraphDev* __restrict__ graphs, const unsigned short* __restrict__ pref_all,
     const unsigned long long* __restrict__ elig_all, const int2* __restrict__ starts,
-    int* __restrict__ out, unsigned long long* __restrict__ sets, int* __restrict__ tickets, int lds_words) {
+    int* __restrict__ out, unsigned long long* __restrict__ sets, int* __restrict__ tickets, int lds_words,
+    unsigned long long* __restrict__ rows_read) {
   // dynamic LDS: candidate set and member set, `lds_words` words each (the widest graph of the
   // group: the fewer bytes a start holds, the more starts a CU runs side by side)
   extern __shared__ unsigned long long clq_lds[];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void clique_starts_group_kernel(
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) np += __shfl_xor(np, off);
   __syncthreads();
-  int size = 0;
+  int size = 0, rows = 1;  // rows of the bit matrix this start reads (statistics)
   if (np > mc) {
     int at = 0;
     while (at < n) {  // every pass advances `at`: at most n / 64 + clique size passes
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(64) void clique_starts_group_kernel(
       const int pick = __builtin_amdgcn_readlane(u, first);
       at += first + 1;
       if (lane == 0) memb[pick >> 6] |= 1ull << (pick & 63);
-      ++size;
+      ++size, ++rows;
       const unsigned long long* r = G.bits + (size_t)pick * words;
       int left = 0;
       __syncthreads();  // all lanes have read cand for the ballot above
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(64) void clique_starts_group_kernel(
   if (lane == 0) {
     out[2 * s] = size;
     out[2 * s + 1] = ticket;
+    atomicAdd(rows_read, (unsigned long long)rows * (unsigned long long)words);  // in words
   }
 }
 
@@ -344,6 +346,8 @@ struct CliqueGroupDev {
   DevBuf<lgicp::GraphDev> table;
   DevBuf<int2> blk, starts;
   DevBuf<int> flags, out, tickets;
+  DevBuf<unsigned long long> rows_read;
+  hipEvent_t ev[2] = {nullptr, nullptr};
   PinBuf h_up, h_down;
   void release() {
     if (device >= 0) {
@@ -353,7 +357,11 @@ struct CliqueGroupDev {
       c.release(), pref.release(), sets.release(), elig.release(), table.release();
       planes_a.release(), planes_b.release();
       blk.release(), starts.release(), flags.release(), out.release(), tickets.release();
-      h_up.release(), h_down.release();
+      h_up.release(), h_down.release(), rows_read.release();
+      for (hipEvent_t& e : ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+      }
       if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
     device = -1;
@@ -370,7 +378,8 @@ int clique_device_max_vertices() { return 65536; }
 // teaser::greedy_clique on `count` bit matrices in device memory, all of them advancing together.
 // Entries with n == 0 are skipped.  Returns false when the device refuses; cliques[i] comes back
 // sorted ascending, equal to the host function's result for graph i.
-bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int count, std::vector<int>* cliques) {
+bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int count, std::vector<int>* cliques,
+                         CliqueTimes* times) {
   using lgicp::GraphDev;
   for (int i = 0; i < count; ++i) cliques[i].clear();
   std::vector<int> ids;
@@ -389,6 +398,11 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     if (hipSetDevice(device) != hipSuccess) return false;
     B.device = device;
   }
+  for (hipEvent_t& e : B.ev)
+    if (!e && hipEventCreate(&e) != hipSuccess) return false;
+  if (B.rows_read.reserve(1) != hipSuccess ||
+      hipMemsetAsync(B.rows_read.p, 0, sizeof(unsigned long long), st) != hipSuccess)
+    return false;
   const bool trace = std::getenv("LGICP_TRACE") != nullptr;
   const auto t_0 = std::chrono::steady_clock::now();
   auto ms_since = [&](std::chrono::steady_clock::time_point t) {
@@ -472,11 +486,13 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
                          B.blk.p, (int)nb, B.c.p, pl_cur);
       first_chunk = false;
     }
+    (void)hipEventRecord(B.ev[0], st);
     for (int r = 0; r < lgicp::HX_ROUNDS; ++r) {
       hipLaunchKernelGGL(lgicp::core_hindex_group_kernel, dim3((unsigned)nb), dim3(256), lds_bytes, st,
                          B.table.p, B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r);
       std::swap(pl_cur, pl_nxt);
     }
+    (void)hipEventRecord(B.ev[1], st);
     n_rounds += lgicp::HX_ROUNDS;
     int* h_flags = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
@@ -484,6 +500,18 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
             hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return false;
+    if (times) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->hindex_ms += ms;
+      times->hindex_launches += lgicp::HX_ROUNDS;
+      // a round reads the bit matrix of every pair it does not skip
+      for (int p = 0; p < P; ++p) {
+        if (settled[p]) continue;
+        int ran = 1;
+        while (ran < lgicp::HX_ROUNDS && h_flags[p * lgicp::HX_ROUNDS + ran - 1] != 0) ++ran;
+        times->hindex_matrix_bytes += (double)ran * tab[p].n * tab[p].words * 8.0;
+      }
+    }
     for (int p = 0; p < P; ++p)
       if (!settled[p] && h_flags[p * lgicp::HX_ROUNDS + lgicp::HX_ROUNDS - 1] == 0) settled[p] = 1, --n_alive;
     if (n_rounds > 4 * max_n + 64) return false;
@@ -571,13 +599,21 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       return false;
     hipLaunchKernelGGL(lgicp::clique_eligible_group_kernel, dim3((max_words + 255) / 256, P), dim3(256), 0, st,
                        B.table.p, B.c.p, B.elig.p, B.tickets.p);
+    (void)hipEventRecord(B.ev[0], st);
     hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<false>, dim3((unsigned)n_s), dim3(64), clq_lds_bytes, st,
-                       B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p, max_words);
+                       B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p, max_words,
+                       B.rows_read.p);
+    (void)hipEventRecord(B.ev[1], st);
     int* h_out = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(h_out, B.out.p, sizeof(int) * 2 * n_s, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return false;
+    if (times) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->starts_ms += ms;
+      times->starts_launches += 1;
+    }
     std::vector<int2> alone;  // improving starts whose members were not kept: run once more
     for (int p = 0; p < P; ++p) {
       Search& s = S[p];
@@ -618,7 +654,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
         return false;
       hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<true>, dim3((unsigned)alone.size()), dim3(64),
                          clq_lds_bytes, st, B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p,
-                         max_words);
+                         max_words, B.rows_read.p);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
     }
   }
@@ -635,7 +671,11 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       return false;
     o += (size_t)tab[p].words;
   }
-  if (hipStreamSynchronize(st) != hipSuccess) return false;
+  unsigned long long rows_words = 0;
+  if (hipMemcpyAsync(&rows_words, B.rows_read.p, sizeof(rows_words), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return false;
+  if (times) times->starts_row_bytes += 8.0 * (double)rows_words;
   o = 0;
   for (int p = 0; p < P; ++p) {
     std::vector<int>& best = cliques[ids[p]];
