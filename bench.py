@@ -238,7 +238,7 @@ def main():
         # weak: every rank its own data; strong: the same list on every rank, cut below
         shard = b if strong else rank * 64 + b
         w = Workload(args.config, pairs=args.pairs, points=args.points, keyframes=args.keyframes,
-                     shard=shard, key_offset=b * KEY_STRIDE)
+                     shard=shard, key_offset=b * KEY_STRIDE, progress=progress)
         if strong:
             mine, keys = shard_workload(w, world, rank)
         else:
@@ -479,6 +479,10 @@ def main():
                 "exhaustive_flops_per_launch": algo_flops,
                 "pruning": exec_flops / algo_flops if algo_flops > 0 else None,
                 "valu_issue_utilisation": issue_util(k_nn),
+                "valu_issue_utilisation_by_pass_class": ({k: v["valu_issue_utilisation"] for k, v in
+                                                          pmc["nn_pruned_kernel_by_pass_class"].items()}
+                                                         if pmc and pmc.get("nn_pruned_kernel_by_pass_class")
+                                                         else None),
                 "exclusive": excl is not None,
                 "exclusive_phase": ({"steps": excl["steps"], "ms_per_step": excl["ms_per_step"],
                                      "stage_ms_per_step": {k: v / excl["steps"]

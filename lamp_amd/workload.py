@@ -138,11 +138,12 @@ class Workload:
     (key_from, key_to); truth: (key_from, key_to) -> 4x4 source->target transform"""
 
     def __init__(self, config="C2", pairs=None, points=None, keyframes=None, shard=0,
-                 pose_noise=(0.0, 0.0), key_offset=0, frame_offset=None):
+                 pose_noise=(0.0, 0.0), key_offset=0, frame_offset=None, progress=None):
         """shard: changes the seed (another batch of the same shape); key_offset: added to every
         key, so that several workloads can live in one engine context; frame_offset: (max rotation
         in deg, max translation in m) of every keyframe's frame against its registered pose
-        (default: C4 (45, 2.5), other configurations none)."""
+        (default: C4 (45, 2.5), other configurations none); progress: called with a line of text
+        every 64 keyframes (large configurations take minutes to generate)."""
         c = dict(CONFIGS[config])
         if pairs is not None:
             c["pairs"] = pairs
@@ -187,6 +188,8 @@ class Workload:
                     nrms = (nrms.astype(np.float64) @ DR).astype(np.float32)
                     R, t = Rs @ DR, ts + Rs @ Dt
                 self.keyframes[k] = (pts, nrms)
+                if progress is not None and len(self.keyframes) % 64 == 0:
+                    progress(f"{len(self.keyframes)}/{self.n_keyframes} keyframes generated")
                 self.true_pose[k] = (R, t)
                 R_reg, t_reg = Rs, ts
                 # registered (odometry) pose = truth + optional drift
