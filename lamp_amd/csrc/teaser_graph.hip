@@ -61,6 +61,18 @@ constexpr int HX_VPB = 4 * HX_VPW;  // per workgroup of four waves: the 64 verti
 constexpr int CLQ_MAX_WORDS = 1024;  // 65536 matches
 constexpr int CLQ_SLOTS = 16;        // member sets a pair can keep per round (+1 for a start run alone)
 
+// sum over the 64 lanes of a wave, in every lane: butterfly within rows of 16 by DPP, the four row
+// sums chained by row broadcasts, total read from lane 63 (no LDS crossbar round trips)
+__device__ __forceinline__ int wave_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);  // row_ror:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // degree of every vertex: one wave per row of the bit matrix
 __global__ __launch_bounds__(256) void graph_degree_kernel(const unsigned long long* __restrict__ bits, int n,
                                                            int words, unsigned short* __restrict__ deg) {
@@ -151,9 +163,7 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
         }
         c += __builtin_popcountll(rw & (gt | eq));
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-      return c;
+      return wave_sum(c);
     };
     // H lies in [lo, hi].  A probe p with count c = count_ge(p) narrows both ends: count_ge never
     // grows with h, so c >= p means p <= H <= c, and c < p means c <= H <= p - 1 (count_ge(c) >=
@@ -222,7 +232,13 @@ __global__ __launch_bounds__(256) void clique_eligible_group_kernel(const GraphD
 // vertex (0: cannot beat the pair's mc), out[2 s + 1] = the slot that holds them as a bit set
 // (-1: none; the host then runs the start once more on its own with kAlone, which always writes
 // its members, into the pair's extra slot).
-template <bool kAlone>
+// A start is a chain of dependent steps (find the next member, fetch its row, intersect, count),
+// and a launch lasts as long as its deepest start, so the chain is kept short: a window of 64
+// entries of the preference order sits in registers (the next one is requested a window ahead),
+// and while a member's row is being intersected the row of the candidate that follows it in the
+// order is already on its way - it is the next member whenever it survives the intersection, which
+// in these dense graphs it mostly does.  WPL = 64-bit words of a row per lane.
+template <bool kAlone, int WPL>
 __global__ __launch_bounds__(64) void clique_starts_group_kernel(
     const GraphDev* __restrict__ graphs, const unsigned short* __restrict__ pref_all,
     const unsigned long long* __restrict__ elig_all, const int2* __restrict__ starts,
@@ -239,45 +255,79 @@ __global__ __launch_bounds__(64) void clique_starts_group_kernel(
   const int v = sv.y, n = G.n, words = G.words, mc = G.mc;
   const unsigned short* pref = pref_all + G.c_off;
   const unsigned long long* elig = elig_all + G.w_off;
-  const unsigned long long* rv = G.bits + (size_t)v * words;
-  int np = 0;
-  for (int w = lane; w < words; w += 64) {
-    const unsigned long long x = rv[w] & elig[w];
-    cand[w] = x;
-    memb[w] = 0;
-    np += __builtin_popcountll(x);
-  }
+  auto load_row = [&](int vtx, unsigned long long (&dst)[WPL]) {
+    const unsigned long long* r = G.bits + (size_t)vtx * words;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) np += __shfl_xor(np, off);
+    for (int q = 0; q < WPL; ++q) {
+      const int w = lane + 64 * q;
+      dst[q] = w < words ? r[w] : 0ull;
+    }
+  };
+  unsigned long long row[WPL], ahead[WPL];
+  load_row(v, row);
+  int np = 0;
+#pragma unroll
+  for (int q = 0; q < WPL; ++q) {
+    const int w = lane + 64 * q;
+    if (w < words) {
+      const unsigned long long x = row[q] & elig[w];
+      cand[w] = x;
+      memb[w] = 0;
+      np += __builtin_popcountll(x);
+    }
+  }
+  np = wave_sum(np);
   __syncthreads();
   int size = 0, rows = 1;  // rows of the bit matrix this start reads (statistics)
   if (np > mc) {
-    int at = 0;
-    while (at < n) {  // every pass advances `at`: at most n / 64 + clique size passes
-      // the first candidate in preference order from `at` on
-      const int idx = at + lane;
-      const int u = idx < n ? (int)pref[idx] : -1;
-      const bool hit = u >= 0 && ((cand[u >> 6] >> (u & 63)) & 1ull);
+    int at = 0;                                        // first entry of the window in registers
+    int u = lane < n ? (int)pref[lane] : -1;           // window [at, at + 64)
+    int u_next = 64 + lane < n ? (int)pref[64 + lane] : -1;
+    int skip = 0;                                      // lanes below it lie behind the cursor
+    int ahead_of = -1;                                 // vertex whose row `ahead` holds
+    for (;;) {
+      // the first candidate in preference order from the cursor on
+      const bool hit = lane >= skip && u >= 0 && ((cand[u >> 6] >> (u & 63)) & 1ull);
       const unsigned long long m = __ballot(hit);
-      if (m == 0) {
+      if (m == 0) {  // window used up: the next one is in registers already
         at += 64;
+        if (at >= n) break;
+        u = u_next;
+        u_next = at + 64 + lane < n ? (int)pref[at + 64 + lane] : -1;
+        skip = 0;
         continue;
       }
       const int first = __builtin_ctzll(m);
       const int pick = __builtin_amdgcn_readlane(u, first);
-      at += first + 1;
+      skip = first + 1;
+      const unsigned long long m2 = m & (m - 1);
+      const int follower = m2 ? __builtin_amdgcn_readlane(u, __builtin_ctzll(m2)) : -1;
       if (lane == 0) memb[pick >> 6] |= 1ull << (pick & 63);
-      ++size, ++rows;
-      const unsigned long long* r = G.bits + (size_t)pick * words;
+      ++size;
+      if (pick == ahead_of) {  // wave-uniform
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) row[q] = ahead[q];
+      } else {
+        load_row(pick, row);
+        ++rows;
+      }
+      if (follower >= 0) {  // requested now, used (perhaps) in the next step
+        load_row(follower, ahead);
+        ++rows;
+      }
+      ahead_of = follower;
       int left = 0;
       __syncthreads();  // all lanes have read cand for the ballot above
-      for (int w = lane; w < words; w += 64) {
-        const unsigned long long x = cand[w] & r[w];
-        cand[w] = x;
-        left += __builtin_popcountll(x);
-      }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) left += __shfl_xor(left, off);
+      for (int q = 0; q < WPL; ++q) {
+        const int w = lane + 64 * q;
+        if (w < words) {
+          const unsigned long long x = cand[w] & row[q];
+          cand[w] = x;
+          left += __builtin_popcountll(x);
+        }
+      }
+      left = wave_sum(left);
       __syncthreads();
       // the start vertex, the members so far and every remaining candidate together cannot beat
       // the best size: whatever this start ends with would be discarded
@@ -564,6 +614,22 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   int n_windows = 0;
   long long n_starts = 0, n_alone = 0;
   const size_t clq_lds_bytes = sizeof(unsigned long long) * 2 * (size_t)max_words;
+  // words of a row per lane, rounded up to the instantiated widths
+  const int wpl = max_words <= 128 ? 2 : max_words <= 256 ? 4 : max_words <= 512 ? 8 : 16;
+  auto launch_starts = [&](bool alone_mode, size_t count) {
+#define LGICP_CLQ_LAUNCH(ALONE, W)                                                                              \
+  hipLaunchKernelGGL((lgicp::clique_starts_group_kernel<ALONE, W>), dim3((unsigned)count), dim3(64), clq_lds_bytes, \
+                     st, B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p, max_words,   \
+                     B.rows_read.p)
+    if (alone_mode) {
+      if (wpl == 2) LGICP_CLQ_LAUNCH(true, 2); else if (wpl == 4) LGICP_CLQ_LAUNCH(true, 4);
+      else if (wpl == 8) LGICP_CLQ_LAUNCH(true, 8); else LGICP_CLQ_LAUNCH(true, 16);
+    } else {
+      if (wpl == 2) LGICP_CLQ_LAUNCH(false, 2); else if (wpl == 4) LGICP_CLQ_LAUNCH(false, 4);
+      else if (wpl == 8) LGICP_CLQ_LAUNCH(false, 8); else LGICP_CLQ_LAUNCH(false, 16);
+    }
+#undef LGICP_CLQ_LAUNCH
+  };
   std::vector<int2> starts;
   for (int round = 0;; ++round) {
     starts.clear();
@@ -600,9 +666,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     hipLaunchKernelGGL(lgicp::clique_eligible_group_kernel, dim3((max_words + 255) / 256, P), dim3(256), 0, st,
                        B.table.p, B.c.p, B.elig.p, B.tickets.p);
     (void)hipEventRecord(B.ev[0], st);
-    hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<false>, dim3((unsigned)n_s), dim3(64), clq_lds_bytes, st,
-                       B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p, max_words,
-                       B.rows_read.p);
+    launch_starts(false, n_s);
     (void)hipEventRecord(B.ev[1], st);
     int* h_out = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
@@ -652,9 +716,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       if (hipMemcpyAsync(B.starts.p, B.h_up.p + tab_bytes, sizeof(int2) * alone.size(), hipMemcpyHostToDevice, st) !=
           hipSuccess)
         return false;
-      hipLaunchKernelGGL(lgicp::clique_starts_group_kernel<true>, dim3((unsigned)alone.size()), dim3(64),
-                         clq_lds_bytes, st, B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p,
-                         max_words, B.rows_read.p);
+      launch_starts(true, alone.size());
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return false;
     }
   }

@@ -115,3 +115,24 @@ def test_c4_batch_recovers_the_true_poses(method, min_recovered):
     n_lost = sum(not (d["status"] == 0 and O.pose_gap(work.truth[p], d["T_icp"])[1] < 0.1)
                  for d, p in zip(lost, work.pairs))
     assert n_lost >= 0.8 * len(work.pairs), n_lost
+
+
+def test_c4_group_results_do_not_depend_on_the_grouping():
+    """The TEASER++ stage advances all pairs of a submit together (one launch carries a step of
+    every pair's clique search, core numbers and rotation search).  What a pair gets must not depend
+    on its company: twelve pairs in one submit against the same pairs one per submit, bit for bit."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=12, keyframes=6, points=8192)
+    c = capi.Context(init_method=capi.INIT_TEASERPP, harris_radius=0.4, transform_thresholding=0)
+    try:
+        work.register(c)
+        together = [capi.result_to_dict(r) for r in c.submit(work.candidates())]
+        alone = [capi.result_to_dict(c.submit([cand])[0]) for cand in work.candidates()]
+    finally:
+        c.close()
+    assert len({d["init_fitness"] for d in together}) > 1      # cliques of different sizes in one group
+    for a, b in zip(together, alone):
+        assert a["init_fitness"] == b["init_fitness"]
+        assert np.array_equal(a["T_init"], b["T_init"])
+        assert np.array_equal(a["T_icp"], b["T_icp"]) and a["status"] == b["status"]
