@@ -271,132 +271,6 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// GNC-TLS rotation over the pairwise differences of a clique of m matches (the host loop is
-// teaser::gnc_rotation): with m in the thousands the m (m - 1) / 2 differences are millions and
-// every one of the up to 100 iterations sums over all of them.  Workgroup (bx, by) owns the
-// differences (i, j), j = bx * 256 + lane, i in the by-th block of GNC_ROWS rows, j > i, recomputed
-// from the m points each time (the row's point is read with wave-uniform addresses).  One
-// launch does everything an iteration needs from a given rotation: residuals, their maximum, the
-// cost under the old weights, the new weights (kept in an m x m array) and the correlation
-// matrix under the new weights for the next rotation.  Each workgroup leaves 11 partial values;
-// gnc_fold_kernel adds them in a fixed order.
-struct GncStep {
-  double R[9];
-  double th1, th2, c, mu;  // weight = 0 above th1, 1 below th2, sqrt(c / res) - mu between
-  int init;                // old weights are 1 (nothing stored yet)
-  int update;              // write the new weights and use them for the correlation
-};
-// One clique of a group: every launch carries an iteration of all cliques still iterating
-// (blockIdx.z), each with its own rotation and thresholds.
-struct GncJobDev {
-  GncStep k;
-  int m;             // clique members
-  int pt_off;        // its first point in the shared point arrays
-  int gx;            // workgroups per row = ceil(m / GNC_THREADS)
-  int part_off;      // its first row of partial values
-  long long w_off;   // its first weight
-  long long out_off; // its row of folded values
-};
-constexpr int GNC_THREADS = 256;
-constexpr int GNC_VALUES = 11;  // H (9), cost, max residual
-constexpr int GNC_ROWS = 32;    // rows of the difference matrix per workgroup
-
-__global__ __launch_bounds__(GNC_THREADS) void gnc_step_kernel(const double* __restrict__ cs_all,
-                                                               const double* __restrict__ cd_all,
-                                                               const GncJobDev* __restrict__ jobs,
-                                                               double* __restrict__ w_all,
-                                                               double* __restrict__ partial_all) {
-  __shared__ double sh[GNC_THREADS / 64][GNC_VALUES];
-  const GncJobDev* J = jobs + blockIdx.z;
-  const int m = J->m, gx = J->gx;
-  const int i_lo = blockIdx.y * GNC_ROWS;
-  if (i_lo >= m || (int)blockIdx.x >= gx) return;  // the grid spans the largest clique of the group
-  const GncStep& k = J->k;
-  const double* cs = cs_all + 3 * (size_t)J->pt_off;
-  const double* cd = cd_all + 3 * (size_t)J->pt_off;
-  double* w = w_all + J->w_off;
-  const int j = blockIdx.x * GNC_THREADS + threadIdx.x;
-  double v[GNC_VALUES];
-#pragma unroll
-  for (int q = 0; q < GNC_VALUES; ++q) v[q] = 0.0;
-  const int jj = j < m ? j : 0;
-  const double sj[3] = {cs[3 * jj], cs[3 * jj + 1], cs[3 * jj + 2]};
-  const double dj[3] = {cd[3 * jj], cd[3 * jj + 1], cd[3 * jj + 2]};
-  const int i_hi = min(i_lo + GNC_ROWS, m);
-  for (int i = i_lo; i < i_hi; ++i) {
-    if (!(j > i && j < m)) continue;
-    double x[3], y[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) x[a] = sj[a] - cs[3 * i + a], y[a] = dj[a] - cd[3 * i + a];
-    double res = 0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const double d = y[a] - (k.R[a * 3] * x[0] + k.R[a * 3 + 1] * x[1] + k.R[a * 3 + 2] * x[2]);
-      res += d * d;
-    }
-    const size_t o = (size_t)i * m + j;
-    const double wo = k.init ? 1.0 : w[o];
-    double wn = wo;
-    if (k.update) {
-      wn = res >= k.th1 ? 0.0 : (res <= k.th2 ? 1.0 : sqrt(k.c / res) - k.mu);
-      w[o] = wn;
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) v[a * 3 + b] += x[a] * wn * y[b];
-    v[9] += wo * res;
-    v[10] = fmax(v[10], res);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int q = 0; q < GNC_VALUES; ++q) {
-    double a = v[q];
-    for (int off = 32; off > 0; off >>= 1) {
-      const double b = __shfl_xor(a, off);
-      a = q == 10 ? fmax(a, b) : a + b;
-    }
-    if (lane == 0) sh[wave][q] = a;
-  }
-  __syncthreads();
-  if (threadIdx.x < GNC_VALUES) {
-    const int q = threadIdx.x;
-    double a = sh[0][q];
-    for (int wv = 1; wv < GNC_THREADS / 64; ++wv) a = q == 10 ? fmax(a, sh[wv][q]) : a + sh[wv][q];
-    partial_all[((size_t)J->part_off + (size_t)blockIdx.y * gx + blockIdx.x) * GNC_VALUES + q] = a;
-  }
-}
-
-// out[job][q] = fold of the job's partial rows: lane t adds rows t, t + 256, ... in order, then
-// the 256 lane sums are added in lane order.  One workgroup per clique.
-__global__ __launch_bounds__(GNC_THREADS) void gnc_fold_kernel(const double* __restrict__ partial_all,
-                                                               const GncJobDev* __restrict__ jobs,
-                                                               double* __restrict__ out_all) {
-  __shared__ double sh[GNC_THREADS][GNC_VALUES];
-  const GncJobDev* J = jobs + blockIdx.x;
-  const double* partial = partial_all + (size_t)J->part_off * GNC_VALUES;
-  const int n = J->gx * ((J->m + GNC_ROWS - 1) / GNC_ROWS);
-  double v[GNC_VALUES];
-#pragma unroll
-  for (int q = 0; q < GNC_VALUES; ++q) v[q] = 0.0;
-  for (int r = threadIdx.x; r < n; r += GNC_THREADS)
-#pragma unroll
-    for (int q = 0; q < GNC_VALUES; ++q) {
-      const double b = partial[(size_t)r * GNC_VALUES + q];
-      v[q] = q == 10 ? fmax(v[q], b) : v[q] + b;
-    }
-#pragma unroll
-  for (int q = 0; q < GNC_VALUES; ++q) sh[threadIdx.x][q] = v[q];
-  __syncthreads();
-  if (threadIdx.x < GNC_VALUES) {
-    const int q = threadIdx.x;
-    double a = sh[0][q];
-    for (int t = 1; t < GNC_THREADS; ++t) a = q == 10 ? fmax(a, sh[t][q]) : a + sh[t][q];
-    out_all[J->out_off * GNC_VALUES + q] = a;
-  }
-}
-
 }  // namespace lgicp
 
 namespace lgicp_detail {
@@ -507,57 +381,7 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
   return LGICP_OK;
 }
 
-// teaser::clique_rotation_host for a group of cliques, with the sums over the pairwise differences
-// on the device: all cliques iterate together, one launch pair (step + fold) and one round trip of
-// 11 sums per clique and iteration; the 3x3 SVDs in between stay on the host.
 namespace {
-struct PinBuf {  // grow-only pinned host array
-  char* p = nullptr;
-  size_t cap = 0;
-  bool reserve(size_t bytes) {
-    if (bytes <= cap) return true;
-    if (p) (void)hipHostFree(p);
-    p = nullptr, cap = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
-    if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
-      p = nullptr;
-      return false;
-    }
-    cap = want;
-    return true;
-  }
-  void release() {
-    if (p) (void)hipHostFree(p);
-    p = nullptr, cap = 0;
-  }
-};
-// Buffers of the rotation search, one set per host thread and reused from group to group;
-// released when the thread ends.  Bound to the device that was current when they were made.
-struct GncGroupDev {
-  int device = -1;
-  DevBuf<double> cs, cd, w, partial, out;
-  DevBuf<lgicp::GncJobDev> table;
-  PinBuf h_up, h_down;
-  void release() {
-    if (device >= 0) {
-      int cur = -1;
-      (void)hipGetDevice(&cur);
-      if (cur != device) (void)hipSetDevice(device);
-      cs.release(), cd.release(), w.release(), partial.release(), out.release(), table.release();
-      h_up.release(), h_down.release();
-      if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
-    }
-    device = -1;
-  }
-  ~GncGroupDev() { release(); }
-};
-
-struct RotJob {
-  const std::vector<double>* cs;
-  const std::vector<double>* cd;
-  double* R;  // [9], out
-};
-
 template <class F>
 void parallel_for(int n, F f) {
   const int nt = std::min(n, (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
@@ -579,148 +403,6 @@ void parallel_for(int n, F f) {
   for (std::thread& t : pool) t.join();
 }
 }  // namespace
-
-static bool clique_rotation_group(int device, hipStream_t st, RotJob* jobs, int count,
-                                  const lgicp::teaser::Params& p) {
-  namespace tz = lgicp::teaser;
-  using lgicp::GncJobDev;
-  using lgicp::GncStep;
-  if (count == 0) return true;
-  thread_local GncGroupDev dev;
-  if (dev.device != device) {
-    dev.release();
-    if (hipSetDevice(device) != hipSuccess) return false;
-    dev.device = device;
-  }
-  double nb2 = p.noise_bound * p.noise_bound;
-  if (nb2 < 1e-16) nb2 = 1e-2;
-  // the weights are m x m doubles per clique: groups of cliques whose weights fit 4 GiB
-  int first = 0;
-  while (first < count) {
-    int last = first;
-    size_t n_w = 0, n_pt = 0, n_part = 0;
-    int max_m = 0, max_gx = 0;
-    struct State {
-      GncJobDev d;
-      int stage = 0, it = 0;  // 0, 1: the two unweighted steps; 2: the GNC loop
-      double mu = 0, prev_cost = INFINITY;
-      bool done = false;
-    };
-    std::vector<State> S;
-    while (last < count) {
-      const int m = (int)(jobs[last].cs->size() / 3);
-      const size_t w_m = (size_t)m * m;
-      if (last > first && (n_w + w_m) * sizeof(double) > (4ull << 30)) break;
-      State s;
-      s.d.m = m;
-      s.d.pt_off = (int)n_pt;
-      s.d.gx = (m + lgicp::GNC_THREADS - 1) / lgicp::GNC_THREADS;
-      s.d.part_off = (int)n_part;
-      s.d.w_off = (long long)n_w;
-      s.d.out_off = (long long)(last - first);
-      std::memset(&s.d.k, 0, sizeof(s.d.k));
-      for (int i = 0; i < 9; ++i) s.d.k.R[i] = jobs[last].R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-      s.d.k.init = 1;
-      S.push_back(s);
-      n_w += w_m, n_pt += (size_t)m, n_part += (size_t)s.d.gx * ((m + lgicp::GNC_ROWS - 1) / lgicp::GNC_ROWS);
-      max_m = std::max(max_m, m), max_gx = std::max(max_gx, s.d.gx);
-      ++last;
-    }
-    const int A = last - first;
-    if (n_part > (size_t)INT_MAX || n_pt > (size_t)INT_MAX) return false;
-    if (dev.cs.reserve(3 * n_pt) != hipSuccess || dev.cd.reserve(3 * n_pt) != hipSuccess ||
-        dev.w.reserve(n_w) != hipSuccess || dev.partial.reserve(n_part * lgicp::GNC_VALUES) != hipSuccess ||
-        dev.out.reserve((size_t)A * lgicp::GNC_VALUES) != hipSuccess || dev.table.reserve((size_t)A) != hipSuccess ||
-        !dev.h_up.reserve(std::max(sizeof(double) * 6 * n_pt, sizeof(GncJobDev) * (size_t)A)) ||
-        !dev.h_down.reserve(sizeof(double) * (size_t)A * lgicp::GNC_VALUES))
-      return false;
-    {
-      double* h = reinterpret_cast<double*>(dev.h_up.p);
-      for (int a = 0; a < A; ++a) {
-        const RotJob& j = jobs[first + a];
-        std::memcpy(h + 3 * (size_t)S[a].d.pt_off, j.cs->data(), sizeof(double) * j.cs->size());
-        std::memcpy(h + 3 * n_pt + 3 * (size_t)S[a].d.pt_off, j.cd->data(), sizeof(double) * j.cd->size());
-      }
-      if (hipMemcpyAsync(dev.cs.p, h, sizeof(double) * 3 * n_pt, hipMemcpyHostToDevice, st) != hipSuccess ||
-          hipMemcpyAsync(dev.cd.p, h + 3 * n_pt, sizeof(double) * 3 * n_pt, hipMemcpyHostToDevice, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess)  // h_up carries the tables from here on
-        return false;
-    }
-    std::vector<int> active;
-    for (;;) {
-      active.clear();
-      for (int a = 0; a < A; ++a)
-        if (!S[a].done) active.push_back(a);
-      if (active.empty()) break;
-      GncJobDev* h_tab = reinterpret_cast<GncJobDev*>(dev.h_up.p);
-      int gm = 0, gg = 0;
-      for (size_t z = 0; z < active.size(); ++z) {
-        h_tab[z] = S[active[z]].d;
-        h_tab[z].out_off = (long long)z;
-        gm = std::max(gm, h_tab[z].m), gg = std::max(gg, h_tab[z].gx);
-      }
-      const double* h_out = reinterpret_cast<const double*>(dev.h_down.p);
-      if (hipMemcpyAsync(dev.table.p, h_tab, sizeof(GncJobDev) * active.size(), hipMemcpyHostToDevice, st) != hipSuccess)
-        return false;
-      hipLaunchKernelGGL(lgicp::gnc_step_kernel, dim3(gg, (gm + lgicp::GNC_ROWS - 1) / lgicp::GNC_ROWS, (unsigned)active.size()),
-                         dim3(lgicp::GNC_THREADS), 0,
-                         st, dev.cs.p, dev.cd.p, dev.table.p, dev.w.p, dev.partial.p);
-      hipLaunchKernelGGL(lgicp::gnc_fold_kernel, dim3((unsigned)active.size()), dim3(lgicp::GNC_THREADS), 0, st,
-                         dev.partial.p, dev.table.p, dev.out.p);
-      if (hipGetLastError() != hipSuccess ||
-          hipMemcpyAsync(dev.h_down.p, dev.out.p, sizeof(double) * active.size() * lgicp::GNC_VALUES,
-                         hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess)
-        return false;
-      for (size_t z = 0; z < active.size(); ++z) {
-        State& s = S[active[z]];
-        const double* out = h_out + z * lgicp::GNC_VALUES;
-        double* R = jobs[first + active[z]].R;
-        GncStep& k = s.d.k;
-        auto next_loop_step = [&] {  // thresholds of GNC iteration s.it
-          k.update = 1;
-          k.th1 = (s.mu + 1) / s.mu * nb2;
-          k.th2 = s.mu / (s.mu + 1) * nb2;
-          k.c = nb2 * s.mu * (s.mu + 1);
-          k.mu = s.mu;
-        };
-        if (s.stage == 0) {
-          // iteration 0 needs the largest residual under the unweighted rotation before it can
-          // set its weights: correlation of unit weights, then the residuals, then the update
-          tz::rotation_from_correlation(out, R);
-          for (int i = 0; i < 9; ++i) k.R[i] = R[i];
-          s.stage = 1;
-        } else if (s.stage == 1) {
-          s.mu = 1.0 / (2.0 * out[10] / nb2 - 1.0);
-          s.prev_cost = INFINITY;
-          s.it = 0;
-          if (!(s.mu > 0) || p.rotation_max_iterations <= 0) {
-            s.done = true;
-          } else {
-            s.stage = 2;
-            next_loop_step();
-          }
-        } else {
-          const double cost = out[9];
-          const double cost_diff = std::fabs(cost - s.prev_cost);
-          s.mu *= p.rotation_gnc_factor;
-          s.prev_cost = cost;
-          ++s.it;
-          if (cost_diff < p.rotation_cost_threshold || !(s.mu > 0) || s.it >= p.rotation_max_iterations) {
-            s.done = true;
-          } else {
-            tz::rotation_from_correlation(out, R);
-            for (int i = 0; i < 9; ++i) k.R[i] = R[i];
-            k.init = 0;
-            next_loop_step();
-          }
-        }
-      }
-    }
-    first = last;
-  }
-  return true;
-}
 
 // GetTeaserInitialAlignment from the keypoints on (IcpLoopComputation.cc:990-1081), first half:
 // descriptor matches and their scale-consistency graph, built on the device from the descriptors
@@ -805,9 +487,9 @@ void teaser_prepare_collect(TeaserJob* job) {
 }
 
 // Second half, for a group of pairs at once: clique, rotation, translation and the acceptance
-// test.  The clique search (teaser_graph.hip) and the sums over the cliques' pairwise differences
-// advance all pairs of the group together on the device; 3x3 algebra, the translation vote and the
-// error metrics are host work spread over threads.  T_out[i] is the guess unless the TEASER++
+// test.  The clique search (teaser_graph.hip) advances all pairs of the group together on the
+// device; rotation (over the chain of the clique), translation vote and error metrics are host
+// work spread over threads.  T_out[i] is the guess unless the TEASER++
 // transform scores at least as well over the matches.
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
                         float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times) {
@@ -841,38 +523,22 @@ int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* con
       cliques[on_host[q]] = tz::greedy_clique(g, g.n >= 2048 ? 8 : 1);
     });
   }
-  // rotation: small cliques on the host, the others together on the device
+  // rotation (GNC-TLS over the chain of the clique's consecutive matches), translation vote and the
+  // acceptance test: a few thousand operations per pair, host work spread over threads
   struct Work {
     std::vector<double> cs, cd;
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
-    bool solved = false;
   };
   std::vector<Work> W((size_t)count);
-  std::vector<int> small;
-  std::vector<RotJob> big;
-  for (int i = 0; i < count; ++i) {
-    n_clique[i] = (int)cliques[i].size();
-    if (cliques[i].size() <= 1) continue;
-    tz::clique_points(jobs[i]->src, jobs[i]->dst, cliques[i], &W[i].cs, &W[i].cd);
-    W[i].solved = true;
-    if (cliques[i].size() < 128)
-      small.push_back(i);
-    else
-      big.push_back(RotJob{&W[i].cs, &W[i].cd, W[i].R});
-  }
-  parallel_for((int)small.size(), [&](int q) {
-    Work& w = W[small[q]];
-    tz::clique_rotation_host(w.cs, w.cd, prm, w.R);
-  });
-  if (!big.empty() && !clique_rotation_group(ctx->cfg.device, st, big.data(), (int)big.size(), prm)) {
-    (void)hipStreamSynchronize(st);  // nothing may still read the buffers when the next group overwrites them
-    return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: rotation search over %d cliques failed on the "
-                "device (%s)", (int)big.size(), hipGetErrorString(hipGetLastError()));
-  }
+  for (int i = 0; i < count; ++i) n_clique[i] = (int)cliques[i].size();
   parallel_for(count, [&](int i) {
     if (jobs[i]->graph.n == 0) return;
     Work& w = W[i];
-    if (w.solved) tz::clique_translation(w.cs, w.cd, w.R, prm, w.t);
+    if (cliques[i].size() > 1) {
+      tz::clique_points(jobs[i]->src, jobs[i]->dst, cliques[i], &w.cs, &w.cd);
+      tz::clique_rotation_host(w.cs, w.cd, prm, w.R);
+      tz::clique_translation(w.cs, w.cd, w.R, prm, w.t);
+    }
     double Ro[9], to[3];
     for (int a = 0; a < 3; ++a) {
       for (int b = 0; b < 3; ++b) Ro[a * 3 + b] = (double)guesses[i][a * 4 + b];

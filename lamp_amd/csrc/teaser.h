@@ -4,9 +4,10 @@
 //
 // Split of the work: descriptor k-NN matches and the O(n^2) scale-consistency graph of the
 // matches are built on the GPU (feature_init.hip) and arrive here as a bit matrix; what is left is
-// graph and small dense algebra on the inlier clique: core numbers, the greedy clique heuristic,
-// graduated non-convexity for the rotation (a weighted 3x3 SVD per iteration over the clique's
-// pairwise differences), and a per-axis truncated-least-squares vote for the translation.
+// graph and small dense algebra on the inlier clique: core numbers, the greedy clique heuristic
+// (both also on the GPU, teaser_graph.hip), graduated non-convexity for the rotation (a weighted
+// 3x3 SVD per iteration over the chain of differences between consecutive clique members), and a
+// per-axis truncated-least-squares vote for the translation.
 // TEASER++ itself is not part of the reference tree; the algorithm follows its publication.
 #pragma once
 
@@ -434,19 +435,21 @@ struct Solution {
   std::vector<int> clique;
 };
 
-// rotation from the pairwise differences of the clique's matches (cs/cd are [m][3]), host version
+// rotation from the clique's matches (cs/cd are [m][3], ascending match ids).  The library's
+// default TIM graph for the rotation stage is the chain (Params::rotation_tim_graph = CHAIN, which
+// the call site leaves alone): member i -> member i + 1, the last one back to the first; m
+// differences, so the whole GNC-TLS loop is a few thousand operations per iteration.
 inline void clique_rotation_host(const std::vector<double>& cs, const std::vector<double>& cd,
                                  const Params& p, double R[9]) {
   const int m = (int)(cs.size() / 3);
-  std::vector<double> st, dt;
-  st.reserve((size_t)3 * m * (m - 1) / 2);
-  dt.reserve((size_t)3 * m * (m - 1) / 2);
-  for (int i = 0; i < m; ++i)
-    for (int j = i + 1; j < m; ++j)
-      for (int c = 0; c < 3; ++c) {
-        st.push_back(cs[3 * j + c] - cs[3 * i + c]);
-        dt.push_back(cd[3 * j + c] - cd[3 * i + c]);
-      }
+  std::vector<double> st((size_t)3 * m), dt((size_t)3 * m);
+  for (int i = 0; i < m; ++i) {
+    const int leaf = i + 1 < m ? i + 1 : 0;
+    for (int c = 0; c < 3; ++c) {
+      st[3 * (size_t)i + c] = cs[3 * leaf + c] - cs[3 * i + c];
+      dt[3 * (size_t)i + c] = cd[3 * leaf + c] - cd[3 * i + c];
+    }
+  }
   gnc_rotation(st, dt, p, R);
 }
 

@@ -115,8 +115,13 @@ __global__ __launch_bounds__(256) void value_planes_kernel(const GraphDev* __res
 // wise: per word of the row, the bit-sliced comparison of 64 values with h (a few operations per
 // plane), an AND and a population count - a cost per vertex that depends on the size of the graph
 // and not on its density, against one LDS gather per neighbour when the values are kept as numbers
-// (these graphs have thousands of neighbours per vertex).
+// (these graphs have thousands of neighbours per vertex).  The probes of one vertex mostly differ in
+// their low bits only, so the state of the comparison after the planes above HX_LOW is kept per word
+// and reused while the probes stay within the same block of 2^HX_LOW values; the vertex's row sits
+// in registers for all its probes.  WPL = 64-bit words of a row per lane.
 // dynamic LDS: nbits planes of `stride` words.
+constexpr int HX_LOW = 6;
+template <int WPL>
 __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* __restrict__ graphs,
                                                                 const int2* __restrict__ blk,
                                                                 const unsigned long long* __restrict__ planes_old,
@@ -146,23 +151,52 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
     }
     // the vertex's own value: lane q' fetches bit q' of it
     const int cv = (int)__ballot(lane < nbits && ((pl[(lane < nbits ? lane : 0) * stride + (v >> 6)] >> (v & 63)) & 1ull));
-    const unsigned long long* row = G.bits + (size_t)v * words;
+    unsigned long long row[WPL], sgt[WPL], seq[WPL];
+    {
+      const unsigned long long* rp = G.bits + (size_t)v * words;
+#pragma unroll
+      for (int k = 0; k < WPL; ++k) {
+        const int w = lane + 64 * k;
+        row[k] = w < words ? rp[w] : 0ull;
+      }
+    }
+    int saved = -1;  // sgt / seq hold the comparison state of thresholds h with h >> HX_LOW == saved
     auto count_ge = [&](int h) {  // neighbours whose value is at least h
+      const int prefix = h >> HX_LOW;
+      const bool reuse = prefix == saved;  // wave-uniform
       int c = 0;
-      for (int w = lane; w < words; w += 64) {
-        const unsigned long long rw = row[w];
-        unsigned long long gt = 0, eq = ~0ull;
-        for (int k = nbits - 1; k >= 0; --k) {
-          const unsigned long long P = pl[k * stride + w];
-          if ((h >> k) & 1) {  // wave-uniform
+#pragma unroll
+      for (int k = 0; k < WPL; ++k) {
+        const int w = lane + 64 * k;
+        if (w >= words) continue;
+        unsigned long long gt, eq;
+        if (reuse) {
+          gt = sgt[k], eq = seq[k];
+        } else {
+          gt = 0, eq = ~0ull;
+          for (int b2 = nbits - 1; b2 >= HX_LOW; --b2) {
+            const unsigned long long P = pl[b2 * stride + w];
+            if ((h >> b2) & 1) {  // wave-uniform
+              eq &= P;
+            } else {
+              gt |= eq & P;
+              eq &= ~P;
+            }
+          }
+          sgt[k] = gt, seq[k] = eq;
+        }
+        for (int b2 = min(nbits, HX_LOW) - 1; b2 >= 0; --b2) {
+          const unsigned long long P = pl[b2 * stride + w];
+          if ((h >> b2) & 1) {
             eq &= P;
           } else {
             gt |= eq & P;
             eq &= ~P;
           }
         }
-        c += __builtin_popcountll(rw & (gt | eq));
+        c += __builtin_popcountll(row[k] & (gt | eq));
       }
+      saved = prefix;
       return wave_sum(c);
     };
     // H lies in [lo, hi].  A probe p with count c = count_ge(p) narrows both ends: count_ge never
@@ -513,9 +547,16 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   static std::once_flag attr_once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(attr_once, [] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 64);
+    const void* fns[4] = {reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<2>),
+                          reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<4>),
+                          reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<8>),
+                          reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<16>)};
+    for (const void* f : fns) {
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 64);
+      if (e != hipSuccess) attr_rc = e;
+    }
   });
+  const int hx_wpl = max_words <= 128 ? 2 : max_words <= 256 ? 4 : max_words <= 512 ? 8 : 16;
   if (attr_rc != hipSuccess) return false;
   unsigned long long* pl_cur = B.planes_a.p;
   unsigned long long* pl_nxt = B.planes_b.p;
@@ -538,8 +579,12 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     }
     (void)hipEventRecord(B.ev[0], st);
     for (int r = 0; r < lgicp::HX_ROUNDS; ++r) {
-      hipLaunchKernelGGL(lgicp::core_hindex_group_kernel, dim3((unsigned)nb), dim3(256), lds_bytes, st,
-                         B.table.p, B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r);
+#define LGICP_HX_LAUNCH(W)                                                                                     \
+  hipLaunchKernelGGL((lgicp::core_hindex_group_kernel<W>), dim3((unsigned)nb), dim3(256), lds_bytes, st, B.table.p, \
+                     B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r)
+      if (hx_wpl == 2) LGICP_HX_LAUNCH(2); else if (hx_wpl == 4) LGICP_HX_LAUNCH(4);
+      else if (hx_wpl == 8) LGICP_HX_LAUNCH(8); else LGICP_HX_LAUNCH(16);
+#undef LGICP_HX_LAUNCH
       std::swap(pl_cur, pl_nxt);
     }
     (void)hipEventRecord(B.ev[1], st);

@@ -3,20 +3,26 @@
  * 949-1081).  TEST INFRASTRUCTURE ONLY: the product library never links or calls this file.
  *
  * PARITY UNPINNED.  TEASER++ is a third-party dependency that is absent from the reference tree
- * (package.xml:25 `teaserpp`, no version pinned; `Matcher::calculateKCorrespondences` and
- * `SolutionEvaluator` exist only in the fork the reference was built against), and the
+ * (package.xml:25 `teaserpp`; install/lamp_http.rosinstall:10-12 names the branch
+ * `feature/pcl-matcher` of MIT-SPARK/TEASER-plusplus, no commit pinned;
+ * `Matcher::calculateKCorrespondences` and `SolutionEvaluator` exist only there), and the
  * reference's only test of this path is commented out (test_loop_computation.cc:101-123).
  * What follows restates the published algorithm (Yang, Shi, Carlone, "TEASER: Fast and
  * Certifiable Point Cloud Registration", and the upstream implementation's structure) with the
  * parameters of the call site: noise_bound 0.5, cbar2 1, no scale estimation, GNC-TLS rotation
- * (100 iterations, factor 1.4, cost threshold 1e-6), inlier selection PMC_HEU.
+ * (100 iterations, factor 1.4, cost threshold 1e-6), inlier selection PMC_HEU.  Parameters the
+ * call site leaves alone keep the library's defaults; the one that matters is
+ * `rotation_tim_graph = INLIER_GRAPH_FORMULATION::CHAIN` (it lives in the same Params struct as
+ * the `inlier_selection_mode` the call site sets): the rotation is estimated from the TIMs of
+ * consecutive clique members (ascending ids, the last one closing the chain to the first), not
+ * from all pairs of them.
  *
  *   1. matches: every source descriptor with each of its k = 5 nearest target descriptors
  *   2. translation-invariant measurements (TIMs) of all match pairs i<j; a pair is
  *      scale-consistent when | |s_j - s_i| - |d_j - d_i| | <= 2 * noise_bound * sqrt(cbar2)
  *   3. greedy maximum-clique heuristic on the consistency graph (k-core ordered, no
  *      backtracking: the heuristic stage of the Parallel Maximum Clique library)
- *   4. GNC-TLS rotation on the TIMs of the clique, weighted SVD alignment per iteration
+ *   4. GNC-TLS rotation on the chain of TIMs of the clique, weighted SVD alignment per iteration
  *   5. component-wise truncated-least-squares translation on the clique's matches
  *   6. the result replaces the odometry guess when its truncated error over the matches
  *      (sum min(d^2 / 100, 1)) is not larger than the guess's
@@ -370,16 +376,17 @@ int lo_teaser_solve(const double* src, const double* dst, int n, double noise_bo
   free(adj);
   *n_clique_out = m;
   if (m <= 1) return 0; /* the solver reports an invalid solution: identity */
-  const size_t M = (size_t)m * (m - 1) / 2;
+  /* chain graph of the clique: member i -> member i + 1, the last -> the first */
+  const size_t M = (size_t)m;
   double* st = (double*)malloc(sizeof(double) * 3 * M);
   double* dt = (double*)malloc(sizeof(double) * 3 * M);
-  size_t q = 0;
-  for (int i = 0; i < m; ++i)
-    for (int j = i + 1; j < m; ++j, ++q)
-      for (int c = 0; c < 3; ++c) {
-        st[3 * q + c] = src[3 * clique_out[j] + c] - src[3 * clique_out[i] + c];
-        dt[3 * q + c] = dst[3 * clique_out[j] + c] - dst[3 * clique_out[i] + c];
-      }
+  for (int i = 0; i < m; ++i) {
+    const int root = clique_out[i], leaf = clique_out[i + 1 < m ? i + 1 : 0];
+    for (int c = 0; c < 3; ++c) {
+      st[3 * (size_t)i + c] = src[3 * leaf + c] - src[3 * root + c];
+      dt[3 * (size_t)i + c] = dst[3 * leaf + c] - dst[3 * root + c];
+    }
+  }
   lo_teaser_gnc_rotation(st, dt, (int)M, noise_bound, rotation_max_iterations, gnc_factor,
                          cost_threshold, R);
   free(st);

@@ -544,8 +544,8 @@ def test_teaser_initial_alignment_matches_oracle(seed, radius):
 
 
 def test_teaser_large_clique_matches_oracle():
-    """From 128 clique members on, the GNC-TLS sums over the clique's pairwise differences run on
-    the device (gnc_step_kernel) instead of the host loop the small cases take."""
+    """A pair whose clique has hundreds of members (twelve thousand points, small Harris radius):
+    clique found on the device, rotation from the chain of the clique's consecutive matches."""
     from lamp_amd import capi
     radius = 0.15
     c = capi.Context(harris_radius=radius)
