@@ -60,9 +60,27 @@ def pmc_summary(config):
 
 
 def pmc_kernel(summary, kernel):
+    """Counters of one kernel; the instantiations of a kernel template (name<...>) are folded into
+    one entry, their per-launch figures weighted by their launches."""
     if not summary:
         return {}
-    return summary.get("kernels", {}).get(kernel, {})
+    ks = summary.get("kernels", {})
+    if kernel in ks:
+        return ks[kernel]
+    parts = [v for k, v in ks.items() if k.startswith(kernel + "<")]
+    if not parts:
+        return {}
+    out = {}
+    for c in set().union(*[set(p) for p in parts]):
+        rows = [p[c] for p in parts if isinstance(p.get(c), dict)]
+        if rows:
+            n = sum(r["launches"] for r in rows)
+            tot = sum(r["sum"] for r in rows)
+            out[c] = {"launches": n, "sum": tot, "mean_per_launch": tot / max(n, 1)}
+    if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+        out["hbm_bytes_per_launch"] = 1024.0 * (2.0 * out["FETCH_SIZE"]["mean_per_launch"] +
+                                                out["WRITE_SIZE"]["mean_per_launch"])
+    return out
 
 
 def cpu_threads_available():
@@ -521,7 +539,7 @@ def main():
         }
         if args.config == "C4":
             # the kernels the C4 step spends its time in belong to the TEASER++ initialisation
-            k_cl = pmc_kernel(pmc, "lgicp::clique_starts_group_kernel<false>")
+            k_cl = pmc_kernel(pmc, "lgicp::clique_starts_group_kernel")
             k_hx = pmc_kernel(pmc, "lgicp::core_hindex_group_kernel")
 
             def hbm_line(kernel, ms, nbytes, launches, k, note):
