@@ -236,6 +236,8 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
     return fail(nullptr, LGICP_E_HIP, "stream / pinned allocation failed");
   }
   ctx->stream = ctx->slot[0].stream;
+  ctx->feature_scratch = std::shared_ptr<FeatureScratch>(new FeatureScratch[FEATURE_LANES],
+                                                         std::default_delete<FeatureScratch[]>());
   ctx->helpers.start(ctx->n_slots - 1);
   *out = ctx;
   return LGICP_OK;
@@ -250,6 +252,8 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   ctx->reg.destroy();
   ctx->teaser_slots.clear();  // device buffers: released while the context's device is current
   if (ctx->matcher) ctx->matcher->release();
+  if (ctx->feature_scratch)
+    for (int l = 0; l < FEATURE_LANES; ++l) ctx->feature_scratch.get()[l].release();
   delete ctx;
 }
 
@@ -533,6 +537,7 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
   const lgicp_config& cfg = ctx->cfg;
   const int n_pairs = (int)bp.pairs.size();
   std::map<int, std::shared_ptr<CloudFeatures>> feat_ptr;
+  std::vector<int> todo;  // clouds whose features have to be computed
   for (int p = 0; p < n_pairs; ++p)
     for (int c : {bp.pairs[p].src_cloud, bp.pairs[p].tgt_cloud})
       if (!feat_ptr.count(c)) {
@@ -542,13 +547,40 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
         std::shared_ptr<CloudFeatures> f = bp.clouds[c].accumulated ? nullptr : kf.features;
         if (!f) {
           f = std::make_shared<CloudFeatures>();
-          const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm_x,
-                                                h_clouds[c].n, f.get());
-          if (rc != LGICP_OK) return rc;
+          todo.push_back(c);
           if (!bp.clouds[c].accumulated) kf.features = f;
         }
         feat_ptr[c] = f;
       }
+  if (!todo.empty()) {
+    // One cloud's sweeps (16k points: a few hundred waves) fill a fraction of the GPU, so several
+    // clouds go side by side: one host thread, stream and scratch set per lane.
+    const int lanes = std::max(1, std::min({(int)todo.size(), FEATURE_LANES, ctx->n_slots}));
+    std::atomic<size_t> next{0};
+    std::atomic<int> rc_all{LGICP_OK};
+    auto run = [&](int lane) {
+      if (hipSetDevice(cfg.device) != hipSuccess) rc_all.store(LGICP_E_HIP);
+      for (;;) {
+        const size_t q = next.fetch_add(1);
+        if (q >= todo.size() || rc_all.load() != LGICP_OK) return;
+        const int c = todo[q];
+        const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm_x, h_clouds[c].n,
+                                              feat_ptr[c].get(), lane);
+        if (rc != LGICP_OK) rc_all.store(rc);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int l = 1; l < lanes; ++l) pool.emplace_back(run, l);
+    run(0);
+    for (std::thread& t : pool) t.join();
+    if (rc_all.load() != LGICP_OK) {
+      // nothing half-made stays behind on a keyframe
+      for (int c : todo)
+        if (!bp.clouds[c].accumulated) ctx->scans.at(bp.clouds[c].key).features.reset();
+      if (rc_all.load() == LGICP_E_HIP && ctx->err.empty()) fail(ctx, LGICP_E_HIP, "feature front end failed");
+      return rc_all.load();
+    }
+  }
   struct FeatView {  // feats[c] as before
     std::map<int, std::shared_ptr<CloudFeatures>>& m;
     const CloudFeatures& operator[](int c) const { return *m.at(c); }

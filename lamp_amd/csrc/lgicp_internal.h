@@ -29,6 +29,7 @@ inline std::string g_create_error;
 struct CloudFeatures;
 struct TeaserJob;
 struct MatcherDev;
+struct FeatureScratch;
 
 struct DevBlock {  // one device allocation shared by the keyframes registered in one call
   char* p = nullptr;
@@ -269,6 +270,7 @@ struct lgicp_ctx {
   // bit matrices and matches of the pairs of a TEASERPP group, reused from submit to submit
   std::vector<std::shared_ptr<lgicp_detail::TeaserJob>> teaser_slots;
   std::shared_ptr<lgicp_detail::MatcherDev> matcher;
+  std::shared_ptr<lgicp_detail::FeatureScratch> feature_scratch;  // [FEATURE_LANES], made on first use
 };
 
 namespace lgicp_detail {
@@ -291,8 +293,10 @@ struct CloudFeatures {
 // constants up (the keyframes must be in ctx->scans under their keys by then).
 int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe* out, bool derive);
 int flush_registrations(lgicp_ctx* ctx);
+// `lane` selects the stream (the context's batch slot streams) and the scratch buffers: calls
+// with different lanes may run at the same time from different host threads
 int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
-                           CloudFeatures* out);
+                           CloudFeatures* out, int lane = 0);
 int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                      const float guess[16], uint32_t seed, float T_out[16], double* score);
 int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
@@ -318,6 +322,15 @@ struct TeaserJob {
     if (h_sd) (void)hipHostFree(h_sd);
   }
 };
+// working buffers of compute_cloud_features, one set per lane (several clouds are processed side
+// by side on different streams), reused from cloud to cloud
+struct FeatureScratch {
+  DevBuf<float> resp, spfh;
+  DevBuf<unsigned char> key, need;
+  DevBuf<float4> kp;
+  void release() { resp.release(), spfh.release(), key.release(), need.release(), kp.release(); }
+};
+constexpr int FEATURE_LANES = 4;
 // buffers of the descriptor matcher, reused from pair to pair (work of successive pairs is
 // ordered by the context's stream)
 struct MatcherDev {

@@ -389,7 +389,7 @@ int lgicp_teaser_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const f
 namespace lgicp_detail {
 
 int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
-                           CloudFeatures* out) {
+                           CloudFeatures* out, int lane) {
   out->idx.clear();
   out->xyz.clear();
   out->feat.clear();
@@ -400,11 +400,13 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   if (cfg.harris_response != 1 || cfg.harris_refine || !cfg.harris_suppression)
     return fail(ctx, LGICP_E_UNSUPPORTED,
                 "only the HARRIS response with non-maxima suppression and no refinement is built");
-  hipStream_t st = ctx->stream;
-  Dev d;
-  float* d_resp = d.alloc<float>((size_t)n);
-  unsigned char* d_key = d.alloc<unsigned char>((size_t)n);
-  if (!d_resp || !d_key) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  if (lane < 0 || lane >= FEATURE_LANES || lane >= ctx->n_slots) lane = 0;
+  hipStream_t st = ctx->slot[lane].stream;
+  FeatureScratch& d = ctx->feature_scratch.get()[lane];
+  if (d.resp.reserve((size_t)n) != hipSuccess || d.key.reserve((size_t)n) != hipSuccess)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  float* d_resp = d.resp.p;
+  unsigned char* d_key = d.key.p;
   const float hr2 = (float)(cfg.harris_radius * cfg.harris_radius);
   HIP_TRY(ctx, launch_harris(d_xyz, d_nrm, n, hr2, (float)cfg.harris_threshold, d_resp, d_key, st));
   std::vector<unsigned char> flags((size_t)n);
@@ -416,21 +418,24 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   const size_t k = out->idx.size();
   if (k == 0) return LGICP_OK;
   // keypoint coordinates: gather on the host from one download of the cloud
-  HIP_TRY(ctx, hipMemcpy(pts.data(), d_xyz, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpyAsync(pts.data(), d_xyz, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
   std::vector<float4> kp(k);
   out->xyz.resize(3 * k);
   for (size_t q = 0; q < k; ++q) {
     kp[q] = pts[out->idx[q]];
     out->xyz[3 * q] = kp[q].x, out->xyz[3 * q + 1] = kp[q].y, out->xyz[3 * q + 2] = kp[q].z;
   }
-  float4* d_kp = d.alloc<float4>(k);
-  unsigned char* d_need = d.alloc<unsigned char>((size_t)n);
-  float* d_spfh = d.alloc<float>((size_t)n * 33);
+  const bool scratch_ok = d.kp.reserve(k) == hipSuccess && d.need.reserve((size_t)n) == hipSuccess &&
+                          d.spfh.reserve((size_t)n * 33) == hipSuccess;
+  float4* d_kp = scratch_ok ? d.kp.p : nullptr;
+  unsigned char* d_need = d.need.p;
+  float* d_spfh = d.spfh.p;
   // descriptors and keypoint coordinates stay on the device for the matcher
   auto block = std::make_shared<DevBlock>();
   if (hipMalloc((void**)&block->p, sizeof(float) * 36 * k) != hipSuccess) block->p = nullptr;
   float* d_out = reinterpret_cast<float*>(block->p);
-  if (!d_kp || !d_need || !d_spfh || !d_out) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  if (!scratch_ok || !d_out) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
   HIP_TRY(ctx, hipMemcpyAsync(d_out + 33 * k, out->xyz.data(), sizeof(float) * 3 * k, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp.data(), sizeof(float4) * k, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemsetAsync(d_spfh, 0, sizeof(float) * (size_t)n * 33, st));
