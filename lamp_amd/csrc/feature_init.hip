@@ -234,25 +234,29 @@ __global__ __launch_bounds__(256) void match_points_kernel(const int* __restrict
 }
 
 // Scale-consistency graph of n matches (TEASER++'s inlier graph when no scale is estimated):
-// bit j of row i is set when | |s_j - s_i| - |d_j - d_i| | <= beta.  A wave owns one 64-bit word
-// column (its 64 matches j sit in registers, one per lane) and 64 rows: the row's match is read
-// with wave-uniform addresses, all lanes test it against their own, and the ballot of the 64 tests
-// is the word of that row; lane r keeps the word of row r, so the 64 words leave in one store.
+// bit j of row i is set when | |s_j - s_i| - |d_j - d_i| | <= beta.  A wave owns one 64 x 64 block
+// of the matrix on or above the diagonal: its 64 column matches j sit in registers, one per lane,
+// the row's match is read with wave-uniform addresses, and all lanes test it against their own.
+// The ballot of the 64 tests is the word of that row (lane r keeps row r's word); the same test
+// results, gathered per lane over the rows, are the word of row j in the mirrored block - the
+// relation is symmetric and so is its arithmetic (the differences change sign, their squares do
+// not), so every pair is tested once and both words leave in one store each.
 __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __restrict__ src,
                                                                 const double* __restrict__ dst,
                                                                 int n, int words, double beta,
                                                                 unsigned long long* __restrict__ bits) {
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int w = blockIdx.x;
-  const int i0 = (blockIdx.y * 4 + wv) * 64;
-  if (i0 >= n) return;  // wave-uniform
+  const int w = blockIdx.x;                // column block
+  const int rb = blockIdx.y * 4 + wv;      // row block
+  if (rb > w || rb >= words) return;       // wave-uniform: blocks below the diagonal are mirrored
+  const int i0 = rb * 64;
   const int j = w * 64 + lane;
   const bool jv = j < n;
   const int jj = jv ? j : 0;
   const double sjx = src[3 * jj], sjy = src[3 * jj + 1], sjz = src[3 * jj + 2];
   const double djx = dst[3 * jj], djy = dst[3 * jj + 1], djz = dst[3 * jj + 2];
   const int rows = min(64, n - i0);
-  unsigned long long mine = 0;
+  unsigned long long mine = 0, mirrored = 0;
   for (int r = 0; r < rows; ++r) {
     const int i = i0 + r;
     const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
@@ -264,10 +268,13 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __
     e = djx - dx, c += e * e;
     e = djy - dy, c += e * e;
     e = djz - dz, c += e * e;
-    const unsigned long long m = __ballot(jv && j != i && fabs(sqrt(a) - sqrt(c)) <= beta);
+    const bool ok = jv && j != i && fabs(sqrt(a) - sqrt(c)) <= beta;
+    const unsigned long long m = __ballot(ok);
     if (lane == r) mine = m;
+    mirrored |= ok ? 1ull << r : 0ull;
   }
   if (lane < rows) bits[(size_t)(i0 + lane) * words + w] = mine;
+  if (rb != w && jv) bits[(size_t)j * words + rb] = mirrored;
 }
 
 
