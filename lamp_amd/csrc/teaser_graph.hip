@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
                                                                 const unsigned long long* __restrict__ planes_old,
                                                                 unsigned long long* __restrict__ planes_new,
                                                                 unsigned short* __restrict__ c_out,
-                                                                int* __restrict__ flags, int r) {
+                                                                int* __restrict__ flags, int r, int far_drops) {
   extern __shared__ __align__(16) unsigned long long pl[];
   __shared__ unsigned short res[HX_VPB];
   const int2 b = blk[blockIdx.x];
@@ -219,7 +219,9 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
           lo = max(lo, c);
           return false;
         };
-        while (lo < hi) {
+        // (in the first rounds the values fall by hundreds or thousands - they start from the
+        // degrees - and the gallop would spend a dozen probes to get there: bisect at once)
+        while (!far_drops && lo < hi) {
           const int probe = hi - step + 1;
           if (probe <= lo || probe_at(probe)) break;
           step <<= 1;
@@ -453,6 +455,7 @@ struct CliqueGroupDev {
   ~CliqueGroupDev() { release(); }
 };
 constexpr int kMaxWindow = 65536;
+constexpr int kFarRounds = 8;  // H-operator rounds that search by bisection alone
 }  // namespace
 
 // largest graph the device path takes: the H-operator kernel keeps one unsigned short per vertex
@@ -581,7 +584,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     for (int r = 0; r < lgicp::HX_ROUNDS; ++r) {
 #define LGICP_HX_LAUNCH(W)                                                                                     \
   hipLaunchKernelGGL((lgicp::core_hindex_group_kernel<W>), dim3((unsigned)nb), dim3(256), lds_bytes, st, B.table.p, \
-                     B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r)
+                     B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r, n_rounds + r < kFarRounds ? 1 : 0)
       if (hx_wpl == 2) LGICP_HX_LAUNCH(2); else if (hx_wpl == 4) LGICP_HX_LAUNCH(4);
       else if (hx_wpl == 8) LGICP_HX_LAUNCH(8); else LGICP_HX_LAUNCH(16);
 #undef LGICP_HX_LAUNCH
