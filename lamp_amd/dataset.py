@@ -262,13 +262,17 @@ def evaluate(data, use_gt_odom=False, filters=None, normals_k=10, **config):
     filters = filters or {}
     ctx = capi.Context(**config)
     try:
-        sizes = []
+        sizes, clouds, normals = [], [], []
         for key, s in enumerate(data.scans):
             xyz, _ = filter_keyed_scan(ctx, s["xyz"], s.get("normals"), filters, seed=key)
             # ConvertPointCloud + AddNormals: the stored normals are dropped and recomputed
             nrm, _ = ctx.compute_normals(xyz, normals_k) if len(xyz) else (np.zeros((0, 3)), None)
-            ctx.add_keyframe(key, xyz, nrm)
+            clouds.append(np.ascontiguousarray(xyz, np.float32))
+            normals.append(np.ascontiguousarray(nrm, np.float32))
             sizes.append(len(xyz))
+        # one registration call for the whole data set: index, covariances and constants of all
+        # scans are built together on the device
+        ctx.add_keyframes(list(range(len(clouds))), clouds, normals)
         for key, (q, t) in enumerate(data.gt_poses if use_gt_odom else data.odom_poses):
             ctx.add_pose(key, q, t)
 
