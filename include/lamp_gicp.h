@@ -108,7 +108,9 @@ typedef struct lgicp_config {
                                  [2] 1 = use the exhaustive 1-NN kernel instead of the pruned
                                  one; [3] first-round radius of the pruned search in mm;
                                  [4] -1 = TEASER++ clique search on the host instead of the device
-                                 (cross-checks), > 0 = diagnostics only: lookup cap in mm;
+                                 (cross-checks), -2 = on the device, every improving start run
+                                 once more on its own (exercises a fallback, same result), > 0 =
+                                 diagnostics only: lookup cap in mm;
                                  [5] bit 0 = host round trip after every outer iteration, bit 1 = no
                                  limit-cycle exit from the outer loop; [6] 1 = no
                                  seeding of a lookup with the previous match, 2 = seeding but no

@@ -520,7 +520,8 @@ int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* con
       else
         on_host.push_back(i);
     }
-    if (on_device && !greedy_clique_group(ctx->cfg.device, st, graphs.data(), count, cliques.data(), times))
+    if (on_device && !greedy_clique_group(ctx->cfg.device, st, graphs.data(), count, cliques.data(), times,
+                                          ctx->cfg.reserved[4] == -2))
       return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: clique search over %d graphs (up to %d matches) "
                   "failed on the device (%s)", on_device, largest, hipGetErrorString(hipGetLastError()));
     // graphs the device path does not take (or reserved[4] = -1): the host search, pairs side by

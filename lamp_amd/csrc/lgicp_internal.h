@@ -352,8 +352,10 @@ struct CliqueTimes {  // hipEvent durations and algorithmic bytes of the two ker
   double starts_ms = 0, starts_row_bytes = 0, hindex_ms = 0, hindex_matrix_bytes = 0;
   uint64_t starts_launches = 0, hindex_launches = 0;
 };
+// rerun_improving: ignore the member sets the windows kept and run every improving start once
+// more on its own (the fallback for a start that found no free slot; a switch for tests)
 bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* graphs, int count,
-                         std::vector<int>* cliques, CliqueTimes* times = nullptr);
+                         std::vector<int>* cliques, CliqueTimes* times = nullptr, bool rerun_improving = false);
 int clique_device_max_vertices();
 // first half: enqueues matcher and consistency graph of one pair on the context's stream and
 // returns; teaser_prepare_collect (after the stream has been synchronised) moves the matched

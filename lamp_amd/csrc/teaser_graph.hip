@@ -466,7 +466,7 @@ int clique_device_max_vertices() { return 65536; }
 // Entries with n == 0 are skipped.  Returns false when the device refuses; cliques[i] comes back
 // sorted ascending, equal to the host function's result for graph i.
 bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int count, std::vector<int>* cliques,
-                         CliqueTimes* times) {
+                         CliqueTimes* times, bool rerun_improving) {
   using lgicp::GraphDev;
   for (int i = 0; i < count; ++i) cliques[i].clear();
   std::vector<int> ids;
@@ -744,7 +744,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       }
       // the serial rule: this start raises the size; the starts after it see the new size
       const int at_s = s.seg_first + improved;
-      const int ticket = h_out[2 * at_s + 1];
+      const int ticket = rerun_improving ? -1 : h_out[2 * at_s + 1];
       s.best_size = h_out[2 * at_s];
       s.best_v = starts[at_s].y;
       if (ticket >= 0) {

@@ -567,20 +567,24 @@ def test_teaser_device_clique_search_equals_host_search():
     from lamp_amd import capi
     host_cfg = [0] * 8
     host_cfg[4] = -1
+    rerun_cfg = [0] * 8
+    rerun_cfg[4] = -2   # device search, every improving start run once more on its own (the fallback
+    #                     of a start that found no free slot for its member set)
     for n, seed, radius in [(3000, 51, 0.5), (6000, 52, 0.3), (12000, 47, 0.15), (9000, 53, 0.2)]:
         src, sn, tgt, tn, _ = F.make_pair(n, seed, rot_deg=4.0, trans=0.4)
         out = []
-        for res in (None, host_cfg):
+        for res in (None, host_cfg, rerun_cfg):
             kw = {} if res is None else {"reserved": (capi.C.c_int * 8)(*res)}
             c = capi.Context(harris_radius=radius, **kw)
             try:
                 out.append(c.teaser_initial_alignment(src, sn, tgt, tn, None))
             finally:
                 c.close()
-        (T_d, used_d, nm_d, nc_d), (T_h, used_h, nm_h, nc_h) = out
+        (T_d, used_d, nm_d, nc_d), (T_h, used_h, nm_h, nc_h), (T_r, used_r, nm_r, nc_r) = out
         assert nm_d == nm_h and nm_d > 10
         assert nc_d == nc_h and used_d == used_h, (n, nm_d, nc_d, nc_h)
         assert np.array_equal(T_d, T_h)
+        assert nc_r == nc_h and used_r == used_h and np.array_equal(T_r, T_h)
 
 
 def test_submit_teaser_init_matches_oracle():
