@@ -22,10 +22,12 @@
 // start_from): candidates = neighbours of the start vertex whose bound exceeds the best size so
 // far, kept as a bit set in LDS; repeatedly the first candidate in preference order (bound, then
 // id, descending) joins the clique and the set is intersected with its row; the start gives up
-// as soon as clique + candidates cannot beat the best size.  Starts are independent given that
-// size, so a window of them runs side by side; the host applies the heuristic's serial rule to
-// the window's results (a start that improves the size ends the window, the starts after it are
-// evaluated again against the new size) and obtains the serial algorithm's clique bit for bit.
+// as soon as clique + candidates cannot beat the best size.  The heuristic is defined serially (a
+// start sees the best size its predecessors left), but a start's result against an older, smaller
+// size decides what it would have found against the current one (see the host loop), so windows
+// of starts run side by side against the size at the window's beginning, every start exactly
+// once, and the host replays the serial rule over the window's results: the serial algorithm's
+// clique, bit for bit.
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -247,14 +249,15 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
 }
 
 // elig bit u = (core number of u) + 1 > mc, for every pair (blockIdx.y); also hands the pair's
-// list slots out afresh (tickets[2 p] = slots taken, tickets[2 p + 1] = lowest improving start so far)
+// set slots out afresh (tickets[p] = slots taken, best_key[p] = best (size, earliest start) so far)
 __global__ __launch_bounds__(256) void clique_eligible_group_kernel(const GraphDev* __restrict__ graphs,
                                                                     const unsigned short* __restrict__ c,
                                                                     unsigned long long* __restrict__ elig,
-                                                                    int* __restrict__ tickets) {
+                                                                    int* __restrict__ tickets,
+                                                                    unsigned long long* __restrict__ best_key) {
   const GraphDev G = graphs[blockIdx.y];
   const int w = blockIdx.x * 256 + threadIdx.x;
-  if (w == 0) tickets[2 * blockIdx.y] = 0, tickets[2 * blockIdx.y + 1] = INT_MAX;
+  if (w == 0) tickets[blockIdx.y] = 0, best_key[blockIdx.y] = 0ull;
   if (w >= G.words) return;
   const unsigned short* cp = c + G.c_off + w * 64;
   unsigned long long m = 0;
@@ -264,10 +267,12 @@ __global__ __launch_bounds__(256) void clique_eligible_group_kernel(const GraphD
   elig[G.w_off + w] = m;
 }
 
-// One wave per start.  starts[s] = (pair, start vertex); out[2 s] = members found besides the start
-// vertex (0: cannot beat the pair's mc), out[2 s + 1] = the slot that holds them as a bit set
+// One wave per start.  starts[s] = (pair, start vertex); out[3 s] = members found besides the start
+// vertex (0: cannot beat the pair's mc), out[3 s + 1] = the slot that holds them as a bit set
 // (-1: none; the host then runs the start once more on its own with kAlone, which always writes
-// its members, into the pair's extra slot).
+// its members, into the pair's extra slot), out[3 s + 2] = for a start that beats mc, the number
+// of its neighbours whose bound exceeds its own result (what the heuristic's entry test would
+// count if the best size were that result: the host needs it to apply the serial rule).
 // A start is a chain of dependent steps (find the next member, fetch its row, intersect, count),
 // and a launch lasts as long as its deepest start, so the chain is kept short: a window of 64
 // entries of the preference order sits in registers (the next one is requested a window ahead),
@@ -277,9 +282,10 @@ __global__ __launch_bounds__(256) void clique_eligible_group_kernel(const GraphD
 template <bool kAlone, int WPL>
 __global__ __launch_bounds__(64) void clique_starts_group_kernel(
     const GraphDev* __restrict__ graphs, const unsigned short* __restrict__ pref_all,
-    const unsigned long long* __restrict__ elig_all, const int2* __restrict__ starts,
-    int* __restrict__ out, unsigned long long* __restrict__ sets, int* __restrict__ tickets, int lds_words,
-    unsigned long long* __restrict__ rows_read) {
+    const unsigned long long* __restrict__ elig_all, const unsigned short* __restrict__ c_all,
+    const int2* __restrict__ starts, int* __restrict__ out, unsigned long long* __restrict__ sets,
+    int* __restrict__ tickets,
+    unsigned long long* __restrict__ best_key, int lds_words, unsigned long long* __restrict__ rows_read) {
   // dynamic LDS: candidate set and member set, `lds_words` words each (the widest graph of the
   // group: the fewer bytes a start holds, the more starts a CU runs side by side)
   extern __shared__ unsigned long long clq_lds[];
@@ -374,14 +380,31 @@ __global__ __launch_bounds__(64) void clique_starts_group_kernel(
       if (left == 0) break;
     }
   }
-  int ticket = -1;
+  int ticket = -1, np_own = 0;
   if (size > 0 && size + 1 > mc) {
-    // The host wants the members of the pair's first improving start in window order only: a
-    // start keeps its set when no start before it has improved so far (the first one always
-    // passes this test; the others that do are few, a sequence of running minima).
+    {
+      // neighbours whose bound exceeds `size`: a subset of the eligible ones (size >= mc)
+      const unsigned short* cv = c_all + G.c_off;
+      load_row(v, row);
+#pragma unroll
+      for (int q = 0; q < WPL; ++q) {
+        const int w = lane + 64 * q;
+        if (w >= words) continue;
+        for (unsigned long long m = row[q] & elig[w]; m; m &= m - 1) {
+          const int u = (w << 6) + __builtin_ctzll(m);
+          np_own += (int)cv[u] + 1 > size;
+        }
+      }
+      np_own = wave_sum(np_own);
+    }
+    // The host wants the members of the window's largest improving clique, the earliest start
+    // among equals: a start keeps its set when it is the best of those finished so far (the one
+    // the host ends up with always passes this test when it finishes; the others that do are few,
+    // a sequence of running maxima).
     int t = CLQ_SLOTS;
     if (!kAlone) {
-      if (lane == 0 && atomicMin(&tickets[2 * sv.x + 1], s) > s) t = atomicAdd(&tickets[2 * sv.x], 1);
+      const unsigned long long key = ((unsigned long long)size << 32) | (0xFFFFFFFFu - (unsigned)s);
+      if (lane == 0 && atomicMax(&best_key[sv.x], key) < key) t = atomicAdd(&tickets[sv.x], 1);
       t = __builtin_amdgcn_readfirstlane(t);
     }
     if (kAlone || t < CLQ_SLOTS) {
@@ -392,8 +415,9 @@ __global__ __launch_bounds__(64) void clique_starts_group_kernel(
     }
   }
   if (lane == 0) {
-    out[2 * s] = size;
-    out[2 * s + 1] = ticket;
+    out[3 * s] = size;
+    out[3 * s + 1] = ticket;
+    out[3 * s + 2] = np_own;
     atomicAdd(rows_read, (unsigned long long)rows * (unsigned long long)words);  // in words
   }
 }
@@ -432,7 +456,7 @@ struct CliqueGroupDev {
   DevBuf<lgicp::GraphDev> table;
   DevBuf<int2> blk, starts;
   DevBuf<int> flags, out, tickets;
-  DevBuf<unsigned long long> rows_read;
+  DevBuf<unsigned long long> rows_read, best_key;
   hipEvent_t ev[2] = {nullptr, nullptr};
   PinBuf h_up, h_down;
   void release() {
@@ -443,7 +467,7 @@ struct CliqueGroupDev {
       c.release(), pref.release(), sets.release(), elig.release(), table.release();
       planes_a.release(), planes_b.release();
       blk.release(), starts.release(), flags.release(), out.release(), tickets.release();
-      h_up.release(), h_down.release(), rows_read.release();
+      h_up.release(), h_down.release(), rows_read.release(), best_key.release();
       for (hipEvent_t& e : ev) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
@@ -527,7 +551,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       B.pref.reserve(total_c) != hipSuccess || B.sets.reserve(total_l) != hipSuccess ||
       B.elig.reserve(total_w) != hipSuccess || B.table.reserve((size_t)P) != hipSuccess ||
       B.blk.reserve(total_blk) != hipSuccess || B.flags.reserve((size_t)P * lgicp::HX_ROUNDS) != hipSuccess ||
-      B.tickets.reserve((size_t)2 * P) != hipSuccess)
+      B.tickets.reserve((size_t)P) != hipSuccess || B.best_key.reserve((size_t)P) != hipSuccess)
     return false;
   const size_t tab_bytes = sizeof(GraphDev) * (size_t)P;
   const size_t up_fixed = tab_bytes + sizeof(int2) * total_blk;
@@ -629,7 +653,6 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     size_t best_loc = 0;
     bool done = false;
     int seg_first = 0, seg_count = 0;   // its starts in the current round
-    std::vector<int> window_pos;
   };
   std::vector<Search> S((size_t)P);
   unsigned short* h_pref = reinterpret_cast<unsigned short*>(B.h_up.p + tab_bytes);
@@ -667,8 +690,8 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   auto launch_starts = [&](bool alone_mode, size_t count) {
 #define LGICP_CLQ_LAUNCH(ALONE, W)                                                                              \
   hipLaunchKernelGGL((lgicp::clique_starts_group_kernel<ALONE, W>), dim3((unsigned)count), dim3(64), clq_lds_bytes, \
-                     st, B.table.p, B.pref.p, B.elig.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p, max_words,   \
-                     B.rows_read.p)
+                     st, B.table.p, B.pref.p, B.elig.p, B.c.p, B.starts.p, B.out.p, B.sets.p, B.tickets.p, B.best_key.p,  \
+                     max_words, B.rows_read.p)
     if (alone_mode) {
       if (wpl == 2) LGICP_CLQ_LAUNCH(true, 2); else if (wpl == 4) LGICP_CLQ_LAUNCH(true, 4);
       else if (wpl == 8) LGICP_CLQ_LAUNCH(true, 8); else LGICP_CLQ_LAUNCH(true, 16);
@@ -687,38 +710,37 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       s.seg_first = (int)starts.size(), s.seg_count = 0;
       if (s.done) continue;
       const int n = tab[p].n;
-      s.window_pos.clear();
       int scan = s.at;
       while (scan < n && s.seg_count < s.win) {
         const int v = s.order[scan++];
-        if (s.K[v] > s.mc) starts.push_back(make_int2(p, v)), s.window_pos.push_back(scan), ++s.seg_count;
+        if (s.K[v] > s.mc) starts.push_back(make_int2(p, v)), ++s.seg_count;
       }
       if (s.seg_count == 0) {
         s.done = true;
         continue;
       }
-      s.at = scan;  // where the pair goes on when no start of the window improves
+      s.at = scan;
       tab[p].mc = s.mc;
       tab[p].list_off = (int)(list_base[p] + (size_t)parity * (lgicp::CLQ_SLOTS + 1) * tab[p].stride);
     }
     const size_t n_s = starts.size();
     if (n_s == 0) break;
     ++n_windows, n_starts += (long long)n_s;
-    if (B.starts.reserve(n_s) != hipSuccess || B.out.reserve(2 * n_s) != hipSuccess ||
-        !B.h_up.reserve(tab_bytes + sizeof(int2) * n_s) || !B.h_down.reserve(sizeof(int) * 2 * n_s))
+    if (B.starts.reserve(n_s) != hipSuccess || B.out.reserve(3 * n_s) != hipSuccess ||
+        !B.h_up.reserve(tab_bytes + sizeof(int2) * n_s) || !B.h_down.reserve(sizeof(int) * 3 * n_s))
       return false;
     std::memcpy(B.h_up.p + tab_bytes, starts.data(), sizeof(int2) * n_s);
     if (!upload_table() ||
         hipMemcpyAsync(B.starts.p, B.h_up.p + tab_bytes, sizeof(int2) * n_s, hipMemcpyHostToDevice, st) != hipSuccess)
       return false;
     hipLaunchKernelGGL(lgicp::clique_eligible_group_kernel, dim3((max_words + 255) / 256, P), dim3(256), 0, st,
-                       B.table.p, B.c.p, B.elig.p, B.tickets.p);
+                       B.table.p, B.c.p, B.elig.p, B.tickets.p, B.best_key.p);
     (void)hipEventRecord(B.ev[0], st);
     launch_starts(false, n_s);
     (void)hipEventRecord(B.ev[1], st);
     int* h_out = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(h_out, B.out.p, sizeof(int) * 2 * n_s, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(h_out, B.out.p, sizeof(int) * 3 * n_s, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return false;
     if (times) {
@@ -726,36 +748,44 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->starts_ms += ms;
       times->starts_launches += 1;
     }
-    std::vector<int2> alone;  // improving starts whose members were not kept: run once more
+    std::vector<int2> alone;  // accepted starts whose members were not kept: run once more
     for (int p = 0; p < P; ++p) {
       Search& s = S[p];
       if (s.done || s.seg_count == 0) continue;
-      int improved = -1;
+      // The serial rule, applied to results that were all computed against the size mc0 of the
+      // window's beginning.  Let mc be the running size.  A start whose clique (with the start
+      // vertex) has more than mc members found exactly what it would have found against mc: all
+      // its members have bounds above mc, so they stay eligible, stay first in preference order
+      // at their step, and keep the candidate count above every give-up test; and a start that
+      // does not beat mc against mc0 does not beat it against mc either (its walk can only end
+      // sooner).  One test of the heuristic does not follow from a result against mc0: it starts
+      // from a vertex only if MORE than mc of its neighbours are eligible, which matters for a
+      // clique of exactly mc + 1 members; the kernel therefore reports that count for the bound
+      // equal to the start's own result (out[3 s + 2]).  Every start is evaluated once.
+      const int mc0 = s.mc;
+      int accepted = -1;
       for (int k = 0; k < s.seg_count; ++k) {
-        const int sz = h_out[2 * (s.seg_first + k)];
-        if (sz > 0 && sz + 1 > s.mc) {
-          improved = k;
-          break;
+        const int* o = h_out + 3 * (size_t)(s.seg_first + k);
+        const int sz = o[0];
+        if (sz <= 0 || sz + 1 <= s.mc) continue;
+        if (sz + 1 >= s.mc + 2 || s.mc == mc0 || o[2] > s.mc) {
+          accepted = k;
+          s.mc = sz + 1;
         }
       }
-      if (improved < 0) {
-        s.win = std::min(s.win * 16, kMaxWindow);
-        continue;
+      if (accepted >= 0) {
+        const int at_s = s.seg_first + accepted;
+        const int ticket = rerun_improving ? -1 : h_out[3 * (size_t)at_s + 1];
+        s.best_size = h_out[3 * (size_t)at_s];
+        s.best_v = starts[at_s].y;
+        if (ticket >= 0) {
+          s.best_loc = (size_t)tab[p].list_off + (size_t)ticket * tab[p].stride;
+        } else {
+          s.best_loc = (size_t)tab[p].list_off + (size_t)lgicp::CLQ_SLOTS * tab[p].stride;
+          alone.push_back(starts[at_s]);
+        }
       }
-      // the serial rule: this start raises the size; the starts after it see the new size
-      const int at_s = s.seg_first + improved;
-      const int ticket = rerun_improving ? -1 : h_out[2 * at_s + 1];
-      s.best_size = h_out[2 * at_s];
-      s.best_v = starts[at_s].y;
-      if (ticket >= 0) {
-        s.best_loc = (size_t)tab[p].list_off + (size_t)ticket * tab[p].stride;
-      } else {
-        s.best_loc = (size_t)tab[p].list_off + (size_t)lgicp::CLQ_SLOTS * tab[p].stride;
-        alone.push_back(starts[at_s]);
-      }
-      s.mc = s.best_size + 1;
-      s.at = s.window_pos[improved];
-      s.win = std::min(std::max(s.win, 64), kMaxWindow);  // improvements come in runs: do not grow yet
+      s.win = std::min(s.win * 16, kMaxWindow);
     }
     if (!alone.empty()) {
       // same table (old mc, old eligibility) as the window they come from
