@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
                                                                 const unsigned long long* __restrict__ planes_old,
                                                                 unsigned long long* __restrict__ planes_new,
                                                                 unsigned short* __restrict__ c_out,
-                                                                int* __restrict__ flags, int r, int far_drops) {
+                                                                int* __restrict__ flags, int r, int mode) {
   extern __shared__ __align__(16) unsigned long long pl[];
   __shared__ unsigned short res[HX_VPB];
   const int2 b = blk[blockIdx.x];
@@ -206,7 +206,54 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
     // count_ge(p) = c).  The new value usually lies just below the old one (the counts jump where
     // many neighbours share a value), so the probes gallop down from the top, then bisect.
     int h = cv;
-    if (cv > 0) {
+    if (mode == 2) {
+      // Coarse round: thresholds are multiples of 2^HX_LOW, for which the low planes do not matter.
+      // k* = the largest k with at least k 2^HX_LOW neighbours at or above k 2^HX_LOW brackets the
+      // H-index within 2^HX_LOW, and min(value, top of that bracket) is still an upper bound of
+      // it - all the iteration needs to stay above the core numbers.  The first rounds, in which
+      // the values fall by thousands from the degrees, get there with a third of the work; the
+      // exact rounds that follow finish the job (and define the result).
+      auto count_coarse = [&](int k) {
+        const int hh = k << HX_LOW;
+        int c = 0;
+#pragma unroll
+        for (int q2 = 0; q2 < WPL; ++q2) {
+          const int w = lane + 64 * q2;
+          if (w >= words) continue;
+          unsigned long long gt = 0, eq = ~0ull;
+          for (int b2 = nbits - 1; b2 >= HX_LOW; --b2) {
+            const unsigned long long P = pl[b2 * stride + w];
+            if ((hh >> b2) & 1) {
+              eq &= P;
+            } else {
+              gt |= eq & P;
+              eq &= ~P;
+            }
+          }
+          c += __builtin_popcountll(row[q2] & (gt | eq));
+        }
+        return wave_sum(c);
+      };
+      const int kv = cv >> HX_LOW;
+      if (kv > 0) {
+        const int c0 = count_coarse(kv);
+        if (c0 < (kv << HX_LOW)) {
+          int lo = c0 >> HX_LOW, hi = kv - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            const int c = count_coarse(mid);
+            if (c >= (mid << HX_LOW)) {
+              lo = mid;
+              hi = min(hi, c >> HX_LOW);
+            } else {
+              hi = mid - 1;
+              lo = max(lo, c >> HX_LOW);
+            }
+          }
+          h = min(cv, (lo << HX_LOW) + (1 << HX_LOW) - 1);
+        }
+      }
+    } else if (cv > 0) {
       const int c0 = count_ge(cv);
       if (c0 < cv) {
         int lo = c0, hi = cv - 1, step = 1;
@@ -223,7 +270,7 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
         };
         // (in the first rounds the values fall by hundreds or thousands - they start from the
         // degrees - and the gallop would spend a dozen probes to get there: bisect at once)
-        while (!far_drops && lo < hi) {
+        while (mode == 0 && lo < hi) {
           const int probe = hi - step + 1;
           if (probe <= lo || probe_at(probe)) break;
           step <<= 1;
@@ -479,7 +526,7 @@ struct CliqueGroupDev {
   ~CliqueGroupDev() { release(); }
 };
 constexpr int kMaxWindow = 65536;
-constexpr int kFarRounds = 8;  // H-operator rounds that search by bisection alone
+constexpr int kCoarseRounds = 16;  // H-operator rounds at the start that work on multiples of 64 (one or more chunks of HX_ROUNDS)
 }  // namespace
 
 // largest graph the device path takes: the H-operator kernel keeps one unsigned short per vertex
@@ -608,7 +655,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     for (int r = 0; r < lgicp::HX_ROUNDS; ++r) {
 #define LGICP_HX_LAUNCH(W)                                                                                     \
   hipLaunchKernelGGL((lgicp::core_hindex_group_kernel<W>), dim3((unsigned)nb), dim3(256), lds_bytes, st, B.table.p, \
-                     B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r, n_rounds + r < kFarRounds ? 1 : 0)
+                     B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r, n_rounds < kCoarseRounds ? 2 : 0)
       if (hx_wpl == 2) LGICP_HX_LAUNCH(2); else if (hx_wpl == 4) LGICP_HX_LAUNCH(4);
       else if (hx_wpl == 8) LGICP_HX_LAUNCH(8); else LGICP_HX_LAUNCH(16);
 #undef LGICP_HX_LAUNCH
@@ -634,7 +681,8 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
         times->hindex_matrix_bytes += (double)ran * tab[p].n * tab[p].words * 8.0;
       }
     }
-    for (int p = 0; p < P; ++p)
+    // (a chunk of coarse rounds settles nothing: its fixed point is not the exact one)
+    for (int p = 0; p < P && n_rounds > kCoarseRounds; ++p)
       if (!settled[p] && h_flags[p * lgicp::HX_ROUNDS + lgicp::HX_ROUNDS - 1] == 0) settled[p] = 1, --n_alive;
     if (n_rounds > 4 * max_n + 64) return false;
   }
