@@ -145,15 +145,34 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int q = 0; q < HX_VPW; ++q) {
-    const int v = b.y + wave * HX_VPW + q;  // wave-uniform
-    if (v >= n) {
+  // The wave's vertices in the order of their values: lane l < HX_VPW reads the value of vertex l
+  // from the planes and ranks it.  The comparison state after the high planes depends on the
+  // threshold's high bits alone, not on the vertex, so it carries over from one vertex to the next
+  // when they share those bits - in a dense graph most values lie close together.
+  int my_val = -1;
+  {
+    const int v = b.y + wave * HX_VPW + lane;
+    if (lane < HX_VPW && v < n) {
+      my_val = 0;
+      for (int k = 0; k < nbits; ++k) my_val |= (int)((pl[k * stride + (v >> 6)] >> (v & 63)) & 1ull) << k;
+    }
+  }
+  int my_rank = 0;
+  for (int j = 0; j < HX_VPW; ++j) {
+    const int vj = __builtin_amdgcn_readlane(my_val, j);
+    my_rank += (vj > my_val || (vj == my_val && j < lane)) ? 1 : 0;
+  }
+  unsigned long long sgt[WPL], seq[WPL];
+  int saved = -1;  // sgt / seq hold the comparison state of thresholds h with h >> HX_LOW == saved
+  for (int turn = 0; turn < HX_VPW; ++turn) {
+    const int q = __builtin_ctzll(__ballot(lane < HX_VPW && my_rank == turn) | (1ull << 63));  // wave-uniform
+    const int v = b.y + wave * HX_VPW + q;
+    const int cv = __builtin_amdgcn_readlane(my_val, q);
+    if (cv < 0) {  // no such vertex
       if (lane == 0) res[wave * HX_VPW + q] = 0;
       continue;
     }
-    // the vertex's own value: lane q' fetches bit q' of it
-    const int cv = (int)__ballot(lane < nbits && ((pl[(lane < nbits ? lane : 0) * stride + (v >> 6)] >> (v & 63)) & 1ull));
-    unsigned long long row[WPL], sgt[WPL], seq[WPL];
+    unsigned long long row[WPL];
     {
       const unsigned long long* rp = G.bits + (size_t)v * words;
 #pragma unroll
@@ -162,7 +181,6 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
         row[k] = w < words ? rp[w] : 0ull;
       }
     }
-    int saved = -1;  // sgt / seq hold the comparison state of thresholds h with h >> HX_LOW == saved
     auto count_ge = [&](int h) {  // neighbours whose value is at least h
       const int prefix = h >> HX_LOW;
       const bool reuse = prefix == saved;  // wave-uniform
