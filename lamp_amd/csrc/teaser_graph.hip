@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
   __shared__ unsigned short res[HX_VPB];
   const int2 b = blk[blockIdx.x];
   const int p = b.x;
+  // a pair whose previous round (all its colours) moved nothing is at rest
   if (r > 0 && flags[p * HX_ROUNDS + r - 1] == 0) return;  // uniform over the workgroup
   const GraphDev G = graphs[p];
   const int n = G.n, words = G.words, nbits = G.nbits, stride = G.stride;
@@ -544,6 +545,7 @@ struct CliqueGroupDev {
   ~CliqueGroupDev() { release(); }
 };
 constexpr int kMaxWindow = 65536;
+constexpr int kColours = 2;  // colours of an H-operator round
 constexpr int kCoarseRounds = 16;  // H-operator rounds at the start that work on multiples of 64 (one or more chunks of HX_ROUNDS)
 }  // namespace
 
@@ -657,10 +659,16 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   int n_rounds = 0, n_alive = P;
   int2* h_blk = reinterpret_cast<int2*>(B.h_up.p + tab_bytes);
   while (n_alive > 0) {  // every round lowers at least one value of a pair or settles it
-    size_t nb = 0;
-    for (int p = 0; p < P; ++p)
-      if (!settled[p])
-        for (int v0 = 0; v0 < tab[p].n; v0 += lgicp::HX_VPB) h_blk[nb++] = make_int2(p, v0);
+    // the workgroups of a round, by colour: 64-vertex group g of a graph has colour g mod kColours
+    size_t nb = 0, colour_first[kColours + 1];
+    for (int col = 0; col < kColours; ++col) {
+      colour_first[col] = nb;
+      for (int p = 0; p < P; ++p)
+        if (!settled[p])
+          for (int v0 = col * lgicp::HX_VPB; v0 < tab[p].n; v0 += kColours * lgicp::HX_VPB)
+            h_blk[nb++] = make_int2(p, v0);
+    }
+    colour_first[kColours] = nb;
     if (hipMemcpyAsync(B.blk.p, h_blk, sizeof(int2) * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemsetAsync(B.flags.p, 0, sizeof(int) * (size_t)P * lgicp::HX_ROUNDS, st) != hipSuccess)
       return false;
@@ -670,15 +678,26 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       first_chunk = false;
     }
     (void)hipEventRecord(B.ev[0], st);
-    for (int r = 0; r < lgicp::HX_ROUNDS; ++r) {
-#define LGICP_HX_LAUNCH(W)                                                                                     \
-  hipLaunchKernelGGL((lgicp::core_hindex_group_kernel<W>), dim3((unsigned)nb), dim3(256), lds_bytes, st, B.table.p, \
-                     B.blk.p, pl_cur, pl_nxt, B.c.p, B.flags.p, r, n_rounds < kCoarseRounds ? 2 : 0)
-      if (hx_wpl == 2) LGICP_HX_LAUNCH(2); else if (hx_wpl == 4) LGICP_HX_LAUNCH(4);
-      else if (hx_wpl == 8) LGICP_HX_LAUNCH(8); else LGICP_HX_LAUNCH(16);
+    // A round goes colour by colour: the groups of one colour are recomputed from the values of
+    // all groups as they stand (the other colours' planes are carried over by a copy), so what one
+    // colour lowers the next already sees - the values then travel several steps per round, and
+    // the rounds are fewer (any order of updates that stays above the core numbers ends at them).
+    for (int r = 0; r < lgicp::HX_ROUNDS; ++r)
+      for (int col = 0; col < kColours; ++col) {
+        const unsigned nbc = (unsigned)(colour_first[col + 1] - colour_first[col]);
+        if (nbc == 0) continue;
+        if (hipMemcpyAsync(pl_nxt, pl_cur, sizeof(unsigned long long) * total_pl, hipMemcpyDeviceToDevice, st) !=
+            hipSuccess)
+          return false;
+#define LGICP_HX_LAUNCH(W)                                                                                  \
+  hipLaunchKernelGGL((lgicp::core_hindex_group_kernel<W>), dim3(nbc), dim3(256), lds_bytes, st, B.table.p,   \
+                     B.blk.p + colour_first[col], pl_cur, pl_nxt, B.c.p, B.flags.p, r,                     \
+                     n_rounds < kCoarseRounds ? 2 : 0)
+        if (hx_wpl == 2) LGICP_HX_LAUNCH(2); else if (hx_wpl == 4) LGICP_HX_LAUNCH(4);
+        else if (hx_wpl == 8) LGICP_HX_LAUNCH(8); else LGICP_HX_LAUNCH(16);
 #undef LGICP_HX_LAUNCH
-      std::swap(pl_cur, pl_nxt);
-    }
+        std::swap(pl_cur, pl_nxt);
+      }
     (void)hipEventRecord(B.ev[1], st);
     n_rounds += lgicp::HX_ROUNDS;
     int* h_flags = reinterpret_cast<int*>(B.h_down.p);
@@ -690,7 +709,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     if (times) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->hindex_ms += ms;
-      times->hindex_launches += lgicp::HX_ROUNDS;
+      times->hindex_launches += lgicp::HX_ROUNDS * kColours;
       // a round reads the bit matrix of every pair it does not skip
       for (int p = 0; p < P; ++p) {
         if (settled[p]) continue;
