@@ -226,6 +226,11 @@ def main():
     args = ap.parse_args()
 
     t_start = time.perf_counter()
+    # stdout carries the one JSON line and nothing else: libraries that print banners there (RCCL
+    # does at communicator creation) are pointed at stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     def progress(what):
         # a line on stderr per phase: long configurations (C4, C5) stay visibly alive
@@ -575,7 +580,7 @@ def main():
                                                       cores, args.harris_radius)
             else:
                 out["cpu_baseline"] = cpu_baseline(w0, min(args.cpu_sample, len(w0.pairs)), cores)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
