@@ -416,7 +416,7 @@ void parallel_for(int n, F f) {
 // and keypoints the clouds' features keep there.  Everything is enqueued on the context's stream
 // and the call returns; the matched keypoints land in the job's pinned buffer.
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                          TeaserJob* job) {
+                          TeaserJob* job, hipStream_t st) {
   namespace tz = lgicp::teaser;
   job->n_matches = 0;
   job->src.clear();
@@ -440,7 +440,7 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
     return LGICP_OK;
   }
   if (!src.d_feat || !tgt.d_feat) return fail(ctx, LGICP_E_INVALID, "cloud features without device copies");
-  hipStream_t st = ctx->stream;
+  if (!st) st = ctx->stream;
   MatcherDev& md = matcher_of(ctx);
   const tz::Params prm;
   tz::BitGraph& g = job->graph;

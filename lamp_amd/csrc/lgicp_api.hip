@@ -595,54 +595,84 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     const bool trace = std::getenv("LGICP_TRACE") != nullptr;  // diagnostics on stderr
     constexpr int kGroup = 128;
     constexpr size_t kGroupBytes = 6ull << 30;  // bit matrices of a group
+    // Two sets of slots: while the clique search of one group runs on the context's stream (chains
+    // of launches that leave much of the GPU idle in their tails), a helper thread enqueues the
+    // matches and graphs of the next group on a second stream.
     std::vector<std::shared_ptr<TeaserJob>>& slots = ctx->teaser_slots;
-    while ((int)slots.size() < kGroup) slots.push_back(std::make_shared<TeaserJob>());
+    while ((int)slots.size() < 2 * kGroup) slots.push_back(std::make_shared<TeaserJob>());
+    hipStream_t prep_stream = ctx->n_slots >= 2 ? ctx->slot[1].stream : ctx->stream;
     std::vector<int> by_size((size_t)n_pairs);
     for (int p = 0; p < n_pairs; ++p) by_size[p] = p;
     std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) {
       return feats[bp.pairs[a].src_cloud].idx.size() > feats[bp.pairs[b].src_cloud].idx.size();
     });
-    int q = 0;
-    while (q < n_pairs) {
-      const auto t_a = std::chrono::steady_clock::now();
-      int g = 0;
-      size_t bytes = 0;
-      int group_pair[kGroup];
+    struct Group {
+      int count = 0, rc = LGICP_OK;
+      double ms = 0;
+      int pair[kGroup];
       TeaserJob* jobs[kGroup];
       const float* guesses[kGroup];
-      while (q < n_pairs && g < kGroup && bytes < kGroupBytes) {
+    };
+    int q = 0;  // next pair (in by_size order) to prepare; touched by one thread at a time
+    auto prepare = [&](Group& G, int half, bool own_thread) {
+      const auto t_a = std::chrono::steady_clock::now();
+      G.count = 0, G.rc = LGICP_OK;
+      if (own_thread && hipSetDevice(cfg.device) != hipSuccess) {
+        G.rc = fail(ctx, LGICP_E_HIP, "hipSetDevice failed");
+        return;
+      }
+      size_t bytes = 0;
+      while (q < n_pairs && G.count < kGroup && bytes < kGroupBytes) {
         const int p = by_size[q++];
         const PairPlan& pp = bp.pairs[p];
-        const int rc = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], slots[g].get());
-        if (rc != LGICP_OK) return rc;
-        bytes += (size_t)slots[g]->graph.n * slots[g]->graph.words * sizeof(uint64_t);
-        group_pair[g] = p, jobs[g] = slots[g].get(), guesses[g] = pp.guess;
-        ++g;
+        TeaserJob* job = slots[(size_t)half * kGroup + G.count].get();
+        G.rc = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], job, prep_stream);
+        if (G.rc != LGICP_OK) return;
+        bytes += (size_t)job->graph.n * job->graph.words * sizeof(uint64_t);
+        G.pair[G.count] = p, G.jobs[G.count] = job, G.guesses[G.count] = pp.guess;
+        ++G.count;
       }
-      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-      for (int j = 0; j < g; ++j) teaser_prepare_collect(jobs[j]);
+      if (hipStreamSynchronize(prep_stream) != hipSuccess) {
+        G.rc = fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: matches and graphs failed on the device (%s)",
+                    hipGetErrorString(hipGetLastError()));
+        return;
+      }
+      for (int j = 0; j < G.count; ++j) teaser_prepare_collect(G.jobs[j]);
+      G.ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
+    };
+    std::unique_ptr<Group> cur(new Group), nxt(new Group);
+    int half = 0;
+    prepare(*cur, half, false);
+    while (cur->rc == LGICP_OK && cur->count > 0) {
       const auto t_b = std::chrono::steady_clock::now();
+      std::thread helper;
+      nxt->count = 0, nxt->rc = LGICP_OK;
+      if (q < n_pairs) helper = std::thread([&] { prepare(*nxt, half ^ 1, true); });
+      const int g = cur->count;
       float T0[kGroup][16];
       int used[kGroup], nc[kGroup];
       CliqueTimes ct;
-      const int rc = teaser_finish_group(ctx, jobs, guesses, g, T0, used, nc, &ct);
+      const int rc = teaser_finish_group(ctx, cur->jobs, cur->guesses, g, T0, used, nc, &ct);
+      if (helper.joinable()) helper.join();
       stats.clique_ms += ct.starts_ms, stats.clique_row_bytes += ct.starts_row_bytes;
       stats.clique_launches += ct.starts_launches;
       stats.hindex_ms += ct.hindex_ms, stats.hindex_matrix_bytes += ct.hindex_matrix_bytes;
       stats.hindex_launches += ct.hindex_launches;
       if (rc != LGICP_OK) return rc;
       for (int j = 0; j < g; ++j) {
-        const int p = group_pair[j];
+        const int p = cur->pair[j];
         out[bp.pairs[p].cand].init_fitness = used[j] ? (double)nc[j] : 0.0;
         std::memcpy(h_pairs[p].guess, T0[j], sizeof(T0[j]));
         if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0[j], sizeof(T0[j]));
       }
       if (trace)
-        std::fprintf(stderr, "[lgicp] teaser group of %d pairs (%d-%d matches): graphs %.1f ms, solve %.1f ms\n", g,
-                     jobs[g - 1]->n_matches, jobs[0]->n_matches,
-                     1e3 * std::chrono::duration<double>(t_b - t_a).count(),
+        std::fprintf(stderr, "[lgicp] teaser group of %d pairs (%d-%d matches): graphs %.1f ms (beside the group "
+                     "before), solve %.1f ms\n", g, cur->jobs[g - 1]->n_matches, cur->jobs[0]->n_matches, cur->ms,
                      1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
+      std::swap(cur, nxt);
+      half ^= 1;
     }
+    if (cur->rc != LGICP_OK) return cur->rc;
     // the slots keep their bit matrices for the next submit unless they have grown large
     size_t held = 0;
     for (auto& sl : slots) held += sl->d_bits.cap * sizeof(unsigned long long);

@@ -360,8 +360,10 @@ int clique_device_max_vertices();
 // first half: enqueues matcher and consistency graph of one pair on the context's stream and
 // returns; teaser_prepare_collect (after the stream has been synchronised) moves the matched
 // keypoints into job->src / job->dst
+// (st: the stream the work is enqueued on, the context's own when null; one caller at a time, the
+// matcher's buffers are shared)
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                          TeaserJob* job);
+                          TeaserJob* job, hipStream_t st = nullptr);
 void teaser_prepare_collect(TeaserJob* job);
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
                         float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times = nullptr);
