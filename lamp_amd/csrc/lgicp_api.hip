@@ -1319,6 +1319,13 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   if (!ctx) return LGICP_E_INVALID;
   if (n && (!cand || !out)) return fail(ctx, LGICP_E_INVALID, "null argument");
   const lgicp_config& cfg = ctx->cfg;
+  const bool trace_submit = std::getenv("LGICP_TRACE") != nullptr;
+  const auto t_submit = std::chrono::steady_clock::now();
+  auto submit_mark = [&](const char* what) {
+    if (trace_submit)
+      std::fprintf(stderr, "[lgicp] submit %s at %.3f ms\n", what,
+                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_submit).count());
+  };
   HIP_TRY(ctx, hipSetDevice(cfg.device));
   {
     // keyframes registered since the last submit: their device work runs on the context's stream
@@ -1424,9 +1431,12 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
     if (!bp.pairs.empty()) plans.push_back(std::move(bp));
   }
 
+  submit_mark("planned");
   plans_ready.store(true, std::memory_order_release);
   worker(0);
+  submit_mark("own part done");
   ctx->helpers.wait();
+  submit_mark("all parts done");
   // device span of the submit: the slots overlap
   ctx->stats.total_ms = *std::max_element(slot_total_ms, slot_total_ms + lgicp_ctx::MAX_SLOTS);
   return rc_all;
