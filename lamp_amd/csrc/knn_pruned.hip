@@ -111,11 +111,13 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
     z = ((Tm[8] * p.x + Tm[9] * p.y) + Tm[10] * p.z) + Tm[11];
   }
   const bool finite = __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
-  float4* const cert = P.cert;  // optional
+  // optional; kept in the order of the query slots (this kernel is its only reader and writer):
+  // 64 consecutive 16-byte entries per wave instead of a gather through qorder
+  float4* const cert = P.cert;
   if (__ballot(finite) == 0) {  // nothing to look up
     if (qi >= 0) {
       P.keys[qi] = NNKEY_NONE;
-      if (cert) cert[qi] = make_float4(x, y, z, 0.f);  // bound 0: never certain
+      if (cert) cert[slot] = make_float4(x, y, z, 0.f);  // bound 0: never certain
     }
     return;
   }
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
     }
     if (cert) {
       // c.xyz: where the query stood when the bound c.w was established
-      const float4 c = cert[qi];
+      const float4 c = cert[slot];
       const float mx = x - c.x, my = y - c.y, mz = z - c.z;
       const float moved = __builtin_amdgcn_sqrtf((mx * mx + my * my) + mz * mz);
       // the float distance arithmetic is off by a few 1e-7 relative; 1e-5 and an absolute 1e-6
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
         // Without a match the bound covers every target.
         float lb = __builtin_fminf(__builtin_fminf(second, ruled), __builtin_fminf(hi, wround * WIDEN));
         if (!found) lb = __builtin_fminf(lb, bestd);
-        cert[qi] = make_float4(x, y, z, finite ? __builtin_amdgcn_sqrtf(lb) * 0.99999f : 0.f);
+        cert[slot] = make_float4(x, y, z, finite ? __builtin_amdgcn_sqrtf(lb) * 0.99999f : 0.f);
       }
     } else {
       P.keys[qi] = kept;
