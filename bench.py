@@ -97,10 +97,10 @@ def cpu_threads_available():
     return max(1, n)
 
 
-def cpu_baseline_c4(work, n_sample, cores, harris_radius):
+def cpu_baseline_c4(work, n_sample, cores, harris_radius, method="teaser"):
     """C4 on the CPU: the oracle's feature front end (Harris keypoints, FPFH, descriptor matches,
-    TEASER++ restatement) from the odometry guess, then GICP (kd-tree, BFGS) from its result — one
-    pair per host thread."""
+    TEASER++ restatement or SAC-IA) from the odometry guess, then GICP (kd-tree, BFGS) from its
+    result — one pair per host thread."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.lib()
@@ -117,8 +117,14 @@ def cpu_baseline_c4(work, n_sample, cores, harris_radius):
         g = np.eye(4, dtype=np.float32)
         g[:3, :3] = np.array(p21.R).reshape(3, 3)
         g[:3, 3] = np.array(p21.t)
-        T0, used, nm, nc = O.teaser_initial_alignment(src, sn, tgt, tn, harris_radius=harris_radius,
-                                                      guess=g)
+        if method == "sac":
+            T0, fit0, _ = O.sac_initial_alignment(src, sn, tgt, tn, harris_radius=harris_radius,
+                                                  iterations=500, guess=g, seed=a * 7919 + b)
+            if not fit0 < 32.0:      # sac_fitness_score_threshold of the base block: rejected
+                return False
+        else:
+            T0, used, nm, nc = O.teaser_initial_alignment(src, sn, tgt, tn, harris_radius=harris_radius,
+                                                          guess=g)
         r = O.gicp_align(O.base_gicp_params(solver=O.SOLVER_BFGS, use_kdtree=1), src, sn, tgt, tn,
                          guess=T0)
         return bool(r["converged"])
@@ -134,7 +140,8 @@ def cpu_baseline_c4(work, n_sample, cores, harris_radius):
     return {"value": len(pairs) / dt, "unit": "pairs/s", "cores": min(cores, len(pairs)), "kind": "port",
             "host_cpus_visible": os.cpu_count(),
             "sample": f"first {len(pairs)} pairs of the same workload, one pair per host thread: CPU "
-                      f"oracle front end (Harris, FPFH, TEASER++ restatement) + GICP (kd-tree, BFGS); "
+                      f"oracle front end (Harris, FPFH, {'SAC-IA' if method == 'sac' else 'TEASER++ restatement'}) "
+                      f"+ GICP (kd-tree, BFGS); "
                       f"{sum(st)} converged"}
 
 
@@ -184,7 +191,8 @@ def cpu_baseline(work, n_sample, cores):
 
 def make_config(capi, args, local_rank, slots=0):
     if args.config == "C4":
-        cfg = capi.default_config(True, device=local_rank, init_method=capi.INIT_TEASERPP,
+        cfg = capi.default_config(True, device=local_rank,
+                                  init_method=capi.INIT_FEATURES if args.c4_init == "sac" else capi.INIT_TEASERPP,
                                   harris_radius=args.harris_radius, transform_thresholding=0)
     else:
         cfg = capi.default_config(True, device=local_rank, init_method=capi.INIT_IDENTITY)
@@ -210,6 +218,8 @@ def main():
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--keyframes", type=int, default=None)
     ap.add_argument("--harris-radius", type=float, default=0.5, help="C4 only")
+    ap.add_argument("--c4-init", default="teaser", choices=["teaser", "sac"],
+                    help="C4 only: TEASER++ (the configuration's method) or SAC-IA global initialisation")
     ap.add_argument("--cpu-sample", type=int, default=256,
                     help="pairs of the same workload timed on the host CPU")
     ap.add_argument("--no-cpu", action="store_true")
@@ -461,7 +471,8 @@ def main():
                              f"{w0.n_points}-pt VLP-16-like keyframes ({w0.n_keyframes} distinct per "
                              f"batch, steps rotate through {n_batches} batch(es)), GICP base-station "
                              f"parameters (corr_dist 0.5, <=200 outer iterations, tf_epsilon 1e-10), "
-                             + ("TEASER++ initialisation from FPFH matches at Harris keypoints "
+                             + (("SAC-IA" if args.c4_init == "sac" else "TEASER++")
+                                + " initialisation from FPFH matches at Harris keypoints "
                                 f"(radius {args.harris_radius}), frames of a pair up to 90 deg / 5 m "
                                 "apart, odometry guess unaware of it, "
                                 if args.config == "C4" else "identity initial guess, ")
@@ -578,7 +589,7 @@ def main():
             cores = cpu_threads_available()
             if args.config == "C4":
                 out["cpu_baseline"] = cpu_baseline_c4(w0, min(args.cpu_sample, cores, len(w0.pairs)),
-                                                      cores, args.harris_radius)
+                                                      cores, args.harris_radius, args.c4_init)
             else:
                 out["cpu_baseline"] = cpu_baseline(w0, min(args.cpu_sample, len(w0.pairs)), cores)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -282,21 +282,6 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __
 
 namespace lgicp_detail {
 
-namespace {
-struct Scratch {
-  std::vector<void*> ptrs;
-  ~Scratch() {
-    for (void* p : ptrs) (void)hipFree(p);
-  }
-  template <typename T>
-  T* alloc(size_t n) {
-    void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-    ptrs.push_back(p);
-    return (T*)p;
-  }
-};
-}  // namespace
 
 static MatcherDev& matcher_of(lgicp_ctx* ctx) {
   if (!ctx->matcher) ctx->matcher = std::make_shared<MatcherDev>();
@@ -329,21 +314,23 @@ static int launch_feature_knn(lgicp_ctx* ctx, MatcherDev& d, const float* d_sf, 
 // SAC-IA on the keypoints/descriptors of two clouds.  score = getFitnessScore() of the
 // keypoint alignment, DBL_MAX when the source has fewer than 3 keypoints or the target none.
 int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                     const float guess[16], uint32_t seed, float T_out[16], double* score) {
+                     const float guess[16], uint32_t seed, float T_out[16], double* score, int lane) {
   std::memcpy(T_out, guess, sizeof(float) * 16);
   *score = DBL_MAX;
   const int n_src = (int)src.idx.size(), n_tgt = (int)tgt.idx.size();
   if (n_src < 3 || n_tgt < 1) return LGICP_OK;
   const int k = std::min(5, n_tgt);  // setCorrespondenceRandomness(5), IcpLoopComputation.cc:697
-  hipStream_t st = ctx->stream;
-  Scratch d;
-  MatcherDev& md = matcher_of(ctx);
+  if (lane < 0 || lane >= FEATURE_LANES || lane >= ctx->n_slots) lane = 0;
+  hipStream_t st = ctx->slot[lane].stream;
+  SacLane& d = ctx->sac_lanes.get()[lane];
+  MatcherDev& md = d.md;
   const float* d_sf = src.d_feat;  // descriptors stay on the device with the cloud's features
   const float* d_tf = tgt.d_feat;
-  float4* d_sk = d.alloc<float4>(n_src);
-  float4* d_tk = d.alloc<float4>(n_tgt);
-  if (!d_sf || !d_tf || md.nn.reserve((size_t)n_src * k) != hipSuccess || !d_sk || !d_tk)
+  if (!d_sf || !d_tf || md.nn.reserve((size_t)n_src * k) != hipSuccess ||
+      d.sk.reserve((size_t)n_src) != hipSuccess || d.tk.reserve((size_t)n_tgt) != hipSuccess)
     return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  float4* d_sk = d.sk.p;
+  float4* d_tk = d.tk.p;
   int* d_nn = md.nn.p;
   std::vector<float4> hs(n_src), ht(n_tgt);
   for (int i = 0; i < n_src; ++i) hs[i] = make_float4(src.xyz[3 * i], src.xyz[3 * i + 1], src.xyz[3 * i + 2], 1.f);
@@ -361,10 +348,11 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
                                                    k, ctx->cfg.sac_iterations, guess, seed);
   const int n_hyp = (int)(hyp.T.size() / 16);
   if (n_hyp == 0) return LGICP_OK;
-  float* d_hyp = d.alloc<float>(hyp.T.size());
   const int n_chunks = (n_src + lgicp::SS_QUERIES - 1) / lgicp::SS_QUERIES;
-  double* d_ef = d.alloc<double>((size_t)2 * n_hyp * n_chunks);
-  if (!d_hyp || !d_ef) return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  if (d.hyp.reserve(hyp.T.size()) != hipSuccess || d.ef.reserve((size_t)2 * n_hyp * n_chunks) != hipSuccess)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  float* d_hyp = d.hyp.p;
+  double* d_ef = d.ef.p;
   HIP_TRY(ctx, hipMemcpyAsync(d_hyp, hyp.T.data(), sizeof(float) * hyp.T.size(), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(lgicp::sac_score_kernel, dim3(n_hyp, n_chunks), dim3(lgicp::SS_THREADS), 0, st,
                      d_hyp, d_sk, n_src, d_tk, n_tgt, 100.0f, d_ef);

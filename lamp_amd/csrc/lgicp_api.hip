@@ -238,6 +238,7 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
   ctx->stream = ctx->slot[0].stream;
   ctx->feature_scratch = std::shared_ptr<FeatureScratch>(new FeatureScratch[FEATURE_LANES],
                                                          std::default_delete<FeatureScratch[]>());
+  ctx->sac_lanes = std::shared_ptr<SacLane>(new SacLane[FEATURE_LANES], std::default_delete<SacLane[]>());
   ctx->helpers.start(ctx->n_slots - 1);
   *out = ctx;
   return LGICP_OK;
@@ -254,6 +255,8 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   if (ctx->matcher) ctx->matcher->release();
   if (ctx->feature_scratch)
     for (int l = 0; l < FEATURE_LANES; ++l) ctx->feature_scratch.get()[l].release();
+  if (ctx->sac_lanes)
+    for (int l = 0; l < FEATURE_LANES; ++l) ctx->sac_lanes.get()[l].release();
   delete ctx;
 }
 
@@ -679,25 +682,44 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     if (held > (8ull << 30))
       for (auto& sl : slots) sl->d_bits.release();
   }
-  for (int p = 0; p < n_pairs && cfg.init_method == LGICP_INIT_FEATURES; ++p) {
-    const PairPlan& pp = bp.pairs[p];
-    float T0[16];
-    double score = 0;
-    // one fixed sampling sequence per (key_from, key_to): results do not depend on how the
-    // candidates were batched
-    const uint32_t seed = 0x5AC1A000u ^ (uint32_t)(cand[pp.cand].key_from * 2654435761ull) ^
-                          (uint32_t)(cand[pp.cand].key_to * 40503ull);
-    const int rc = sac_align_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], pp.guess,
-                                    seed, T0, &score);
-    if (rc != LGICP_OK) return rc;
-    out[pp.cand].init_fitness = score;
-    std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
-    if (!(score < cfg.sac_fitness_score_threshold)) {
-      init_rejected[p] = 1;
-      h_state[p].active = 0;
-      h_state[p].failed = 1;
-    }
-    if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
+  if (cfg.init_method == LGICP_INIT_FEATURES && n_pairs > 0) {
+    // A pair's alignment is two small launches with a host step between them (hypotheses from the
+    // 5-NN table): several pairs go side by side, one host thread, stream and buffer set per lane.
+    const int lanes = std::max(1, std::min({n_pairs, FEATURE_LANES, ctx->n_slots}));
+    std::atomic<int> next{0}, rc_all{LGICP_OK};
+    auto run = [&](int lane) {
+      if (hipSetDevice(cfg.device) != hipSuccess) rc_all.store(LGICP_E_HIP);
+      for (;;) {
+        const int p = next.fetch_add(1);
+        if (p >= n_pairs || rc_all.load() != LGICP_OK) return;
+        const PairPlan& pp = bp.pairs[p];
+        float T0[16];
+        double score = 0;
+        // one fixed sampling sequence per (key_from, key_to): results do not depend on how the
+        // candidates were batched
+        const uint32_t seed = 0x5AC1A000u ^ (uint32_t)(cand[pp.cand].key_from * 2654435761ull) ^
+                              (uint32_t)(cand[pp.cand].key_to * 40503ull);
+        const int rc = sac_align_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], pp.guess, seed, T0,
+                                        &score, lane);
+        if (rc != LGICP_OK) {
+          rc_all.store(rc);
+          return;
+        }
+        out[pp.cand].init_fitness = score;
+        std::memcpy(h_pairs[p].guess, T0, sizeof(T0));
+        if (!(score < cfg.sac_fitness_score_threshold)) {
+          init_rejected[p] = 1;
+          h_state[p].active = 0;
+          h_state[p].failed = 1;
+        }
+        if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int l = 1; l < lanes; ++l) pool.emplace_back(run, l);
+    run(0);
+    for (std::thread& t : pool) t.join();
+    if (rc_all.load() != LGICP_OK) return rc_all.load();
   }
   return LGICP_OK;
 }

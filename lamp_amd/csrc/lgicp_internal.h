@@ -30,6 +30,7 @@ struct CloudFeatures;
 struct TeaserJob;
 struct MatcherDev;
 struct FeatureScratch;
+struct SacLane;
 
 struct DevBlock {  // one device allocation shared by the keyframes registered in one call
   char* p = nullptr;
@@ -270,7 +271,8 @@ struct lgicp_ctx {
   // bit matrices and matches of the pairs of a TEASERPP group, reused from submit to submit
   std::vector<std::shared_ptr<lgicp_detail::TeaserJob>> teaser_slots;
   std::shared_ptr<lgicp_detail::MatcherDev> matcher;
-  std::shared_ptr<lgicp_detail::FeatureScratch> feature_scratch;  // [FEATURE_LANES], made on first use
+  std::shared_ptr<lgicp_detail::FeatureScratch> feature_scratch;  // [FEATURE_LANES]
+  std::shared_ptr<lgicp_detail::SacLane> sac_lanes;               // [FEATURE_LANES]
 };
 
 namespace lgicp_detail {
@@ -297,8 +299,9 @@ int flush_registrations(lgicp_ctx* ctx);
 // with different lanes may run at the same time from different host threads
 int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
                            CloudFeatures* out, int lane = 0);
+// (lane: stream and buffers, as for compute_cloud_features)
 int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                     const float guess[16], uint32_t seed, float T_out[16], double* score);
+                     const float guess[16], uint32_t seed, float T_out[16], double* score, int lane = 0);
 int teaser_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                         const float guess[16], float T_out[16], int* used, int* n_matches,
                         int* n_clique);
@@ -337,6 +340,15 @@ struct MatcherDev {
   DevBuf<float> part_d;
   DevBuf<int> part_i, nn;
   void release() { part_d.release(), part_i.release(), nn.release(); }
+};
+// buffers of one SAC-IA alignment, one set per lane (several pairs are aligned side by side on
+// different streams), reused from pair to pair
+struct SacLane {
+  MatcherDev md;
+  DevBuf<float4> sk, tk;
+  DevBuf<float> hyp;
+  DevBuf<double> ef;
+  void release() { md.release(), sk.release(), tk.release(), hyp.release(), ef.release(); }
 };
 // teaser::greedy_clique on a bit matrix in device memory (teaser_graph.hip): core numbers and the
 // windows of starts run on `st`; false when the device refuses
