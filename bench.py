@@ -553,7 +553,7 @@ def main():
                         "durations from the one-stream phase.",
             },
         }
-        if args.config == "C4":
+        if args.config == "C4" and args.c4_init == "teaser":
             # the kernels the C4 step spends its time in belong to the TEASER++ initialisation
             k_cl = pmc_kernel(pmc, "lgicp::clique_starts_group_kernel")
             k_hx = pmc_kernel(pmc, "lgicp::core_hindex_group_kernel")
