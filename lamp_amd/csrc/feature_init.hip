@@ -437,7 +437,7 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
   const size_t n_words = (size_t)n * g.words;
   const size_t sd_bytes = sizeof(double) * 6 * (size_t)n;
   if (job->h_sd_cap < sd_bytes) {
-    if (job->h_sd) (void)hipHostFree(job->h_sd);
+    park_pinned_memory(job->h_sd);  // freed when the next submit begins: no device-wide wait here
     job->h_sd = nullptr, job->h_sd_cap = 0;
     const size_t want = sd_bytes + sd_bytes / 4;
     if (hipHostMalloc((void**)&job->h_sd, want, hipHostMallocDefault) != hipSuccess) {

@@ -32,6 +32,36 @@
 
 #include "lgicp_internal.h"
 
+namespace lgicp_detail {
+
+static std::mutex g_parked_mutex;
+static std::vector<void*> g_parked, g_parked_pinned;
+
+void park_device_memory(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_parked_mutex);
+  g_parked.push_back(p);
+}
+
+void park_pinned_memory(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_parked_mutex);
+  g_parked_pinned.push_back(p);
+}
+
+void free_parked_device_memory() {
+  std::vector<void*> dev, pinned;
+  {
+    std::lock_guard<std::mutex> lk(g_parked_mutex);
+    dev.swap(g_parked);
+    pinned.swap(g_parked_pinned);
+  }
+  for (void* p : dev) (void)hipFree(p);
+  for (void* p : pinned) (void)hipHostFree(p);
+}
+
+}  // namespace lgicp_detail
+
 namespace {
 
 inline int round_up(int n, int m) { return ((n + m - 1) / m) * m; }
@@ -245,6 +275,7 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
 }
 
 void lgicp_destroy(lgicp_ctx* ctx) {
+  free_parked_device_memory();
   if (!ctx) return;
   ctx->helpers.shutdown();
   (void)hipSetDevice(ctx->cfg.device);
@@ -1349,6 +1380,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_submit).count());
   };
   HIP_TRY(ctx, hipSetDevice(cfg.device));
+  free_parked_device_memory();
   {
     // keyframes registered since the last submit: their device work runs on the context's stream
     const int rc = flush_registrations(ctx);

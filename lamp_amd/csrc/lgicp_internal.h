@@ -75,13 +75,22 @@ struct Keyframe {
   }
 };
 
+// hipFree waits for all work of the device, whichever stream it is on: a buffer that is outgrown
+// in the middle of a submit (the groups of a feature-based initialisation differ from batch to
+// batch) would stall every stage running beside the caller, once per buffer.  Outgrown buffers are
+// parked instead and freed when the next submit begins (free_parked_device_memory), with nothing
+// of the context in flight.  Both are safe to call from any thread.
+void park_device_memory(void* p);
+void park_pinned_memory(void* p);  // same for hipHostMalloc'ed memory
+void free_parked_device_memory();
+
 template <typename T>
 struct DevBuf {  // grow-only device array
   T* p = nullptr;
   size_t cap = 0;
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
+    park_device_memory(p);
     p = nullptr;
     cap = 0;
     size_t want = n + n / 4 + 16;

@@ -498,7 +498,7 @@ struct PinBuf {  // grow-only pinned host array
   size_t cap = 0;
   bool reserve(size_t bytes) {
     if (bytes <= cap) return true;
-    if (p) (void)hipHostFree(p);
+    park_pinned_memory(p);
     p = nullptr, cap = 0;
     const size_t want = bytes + bytes / 4 + 4096;
     if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
@@ -589,7 +589,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   // ---- layout ----------------------------------------------------------------------------------
   std::vector<GraphDev> tab((size_t)P);
   std::vector<size_t> list_base((size_t)P);
-  size_t total_c = 0, total_w = 0, total_l = 0, total_blk = 0, total_pl = 0, max_planes = 0;
+  size_t total_c = 0, total_w = 0, total_l = 0, total_blk = 0, total_pl = 0;
   int max_n = 0, max_words = 0;
   for (int p = 0; p < P; ++p) {
     const CliqueGraph& g = gr[ids[p]];
@@ -604,7 +604,6 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     t.stride = (g.words + 1) & ~1;
     t.pl_off = (int)total_pl;
     total_pl += (size_t)t.nbits * t.stride;
-    max_planes = std::max(max_planes, (size_t)t.nbits * t.stride);
     list_base[p] = total_l;
     total_l += (size_t)2 * (lgicp::CLQ_SLOTS + 1) * t.stride;
     total_c += (size_t)t.n_pad;
@@ -637,7 +636,6 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   for (int p = 0; p < P; ++p)
     hipLaunchKernelGGL(lgicp::graph_degree_kernel, dim3((tab[p].n + 3) / 4), dim3(256), 0, st, tab[p].bits,
                        tab[p].n, tab[p].words, B.c.p + tab[p].c_off);
-  const size_t lds_bytes = sizeof(unsigned long long) * max_planes;
   static std::once_flag attr_once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(attr_once, [] {
@@ -650,8 +648,18 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
       if (e != hipSuccess) attr_rc = e;
     }
   });
-  const int hx_wpl = max_words <= 128 ? 2 : max_words <= 256 ? 4 : max_words <= 512 ? 8 : 16;
   if (attr_rc != hipSuccess) return false;
+  // The kernel keeps a vertex's row in registers, so it is instantiated per row width; the graphs of
+  // a group are launched by width class, each class with the instantiation and the LDS size it
+  // needs (one graph of more than 32,768 vertices would otherwise put every graph of its group on
+  // the widest instantiation: a quarter of the occupancy, arrays in scratch memory).
+  constexpr int kClasses = 4;
+  auto class_of = [](int words) { return words <= 128 ? 0 : words <= 256 ? 1 : words <= 512 ? 2 : 3; };
+  size_t class_lds[kClasses] = {0, 0, 0, 0};
+  for (int p = 0; p < P; ++p) {
+    size_t& b = class_lds[class_of(tab[p].words)];
+    b = std::max(b, sizeof(unsigned long long) * (size_t)tab[p].nbits * tab[p].stride);
+  }
   unsigned long long* pl_cur = B.planes_a.p;
   unsigned long long* pl_nxt = B.planes_b.p;
   bool first_chunk = true;
@@ -660,15 +668,16 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   int2* h_blk = reinterpret_cast<int2*>(B.h_up.p + tab_bytes);
   while (n_alive > 0) {  // every round lowers at least one value of a pair or settles it
     // the workgroups of a round, by colour: 64-vertex group g of a graph has colour g mod kColours
-    size_t nb = 0, colour_first[kColours + 1];
-    for (int col = 0; col < kColours; ++col) {
-      colour_first[col] = nb;
-      for (int p = 0; p < P; ++p)
-        if (!settled[p])
-          for (int v0 = col * lgicp::HX_VPB; v0 < tab[p].n; v0 += kColours * lgicp::HX_VPB)
-            h_blk[nb++] = make_int2(p, v0);
-    }
-    colour_first[kColours] = nb;
+    size_t nb = 0, part_first[kColours * kClasses + 1];  // parts: colour-major, then width class
+    for (int col = 0; col < kColours; ++col)
+      for (int cls = 0; cls < kClasses; ++cls) {
+        part_first[col * kClasses + cls] = nb;
+        for (int p = 0; p < P; ++p)
+          if (!settled[p] && class_of(tab[p].words) == cls)
+            for (int v0 = col * lgicp::HX_VPB; v0 < tab[p].n; v0 += kColours * lgicp::HX_VPB)
+              h_blk[nb++] = make_int2(p, v0);
+      }
+    part_first[kColours * kClasses] = nb;
     if (hipMemcpyAsync(B.blk.p, h_blk, sizeof(int2) * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemsetAsync(B.flags.p, 0, sizeof(int) * (size_t)P * lgicp::HX_ROUNDS, st) != hipSuccess)
       return false;
@@ -684,18 +693,22 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     // the rounds are fewer (any order of updates that stays above the core numbers ends at them).
     for (int r = 0; r < lgicp::HX_ROUNDS; ++r)
       for (int col = 0; col < kColours; ++col) {
-        const unsigned nbc = (unsigned)(colour_first[col + 1] - colour_first[col]);
-        if (nbc == 0) continue;
+        if (part_first[(col + 1) * kClasses] == part_first[col * kClasses]) continue;
         if (hipMemcpyAsync(pl_nxt, pl_cur, sizeof(unsigned long long) * total_pl, hipMemcpyDeviceToDevice, st) !=
             hipSuccess)
           return false;
-#define LGICP_HX_LAUNCH(W)                                                                                  \
-  hipLaunchKernelGGL((lgicp::core_hindex_group_kernel<W>), dim3(nbc), dim3(256), lds_bytes, st, B.table.p,   \
-                     B.blk.p + colour_first[col], pl_cur, pl_nxt, B.c.p, B.flags.p, r,                     \
-                     n_rounds < kCoarseRounds ? 2 : 0)
-        if (hx_wpl == 2) LGICP_HX_LAUNCH(2); else if (hx_wpl == 4) LGICP_HX_LAUNCH(4);
-        else if (hx_wpl == 8) LGICP_HX_LAUNCH(8); else LGICP_HX_LAUNCH(16);
+        for (int cls = 0; cls < kClasses; ++cls) {
+          const size_t first = part_first[col * kClasses + cls];
+          const unsigned nbc = (unsigned)(part_first[col * kClasses + cls + 1] - first);
+          if (nbc == 0) continue;
+#define LGICP_HX_LAUNCH(W)                                                                                        \
+  hipLaunchKernelGGL((lgicp::core_hindex_group_kernel<W>), dim3(nbc), dim3(256), class_lds[cls], st, B.table.p,   \
+                     B.blk.p + first, pl_cur, pl_nxt, B.c.p, B.flags.p, r, n_rounds < kCoarseRounds ? 2 : 0)
+          if (cls == 0) LGICP_HX_LAUNCH(2); else if (cls == 1) LGICP_HX_LAUNCH(4);
+          else if (cls == 2) LGICP_HX_LAUNCH(8); else LGICP_HX_LAUNCH(16);
 #undef LGICP_HX_LAUNCH
+          if (times) ++times->hindex_launches;
+        }
         std::swap(pl_cur, pl_nxt);
       }
     (void)hipEventRecord(B.ev[1], st);
@@ -709,7 +722,6 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     if (times) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->hindex_ms += ms;
-      times->hindex_launches += lgicp::HX_ROUNDS * kColours;
       // a round reads the bit matrix of every pair it does not skip
       for (int p = 0; p < P; ++p) {
         if (settled[p]) continue;
