@@ -151,6 +151,10 @@ __global__ void assemble_kernel(const SegmentDev* __restrict__ segs) {
     if (s.src_cov) {  // normals are copied unrotated, so the covariances built from them are too
 #pragma unroll
       for (int k = 0; k < 6; ++k) s.dst_cov[6 * (size_t)i + k] = s.src_cov[6 * (size_t)i + k];
+      const float4 cn = s.src_cnrm[i];
+      s.dst_cnrm[i] = cn;
+      s.dst_rec[2 * (size_t)i] = p;
+      s.dst_rec[2 * (size_t)i + 1] = cn;
     }
   }
 }

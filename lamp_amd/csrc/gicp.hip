@@ -42,9 +42,48 @@ __host__ __device__ constexpr int uu_slot(int k, int l) {
 // it waited on its gathers.  Each lane still builds a and b of its own point; a wave passes them
 // through its private LDS rows so that lane l can feed A[l & 15][l >> 4] and B[l >> 4][l & 15].
 typedef double red_d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_cov6(const double* __restrict__ p, double c[6]) {
+  const double2* const q = reinterpret_cast<const double2*>(p);  // 16-byte aligned: 48-byte stride
+  const double2 a = q[0], b = q[1], d = q[2];
+  c[0] = a.x, c[1] = a.y, c[2] = b.x, c[3] = b.y, c[4] = d.x, c[5] = d.y;
+}
 constexpr int RM_ROWS_A = 13, RM_ROWS_B = 10;
 constexpr int RM_STR = 65;  // doubles per staged row (64 points + 1: operand reads spread over the banks)
 
+// S = R C1 R^T + C2 with C1, C2 as c00 c01 c02 c11 c12 c22 (gicp.hpp:485-493)
+__device__ __forceinline__ void sandwich(const double R[9], const double c1[6], const double c2[6],
+                                         double& s00, double& s01, double& s02, double& s11,
+                                         double& s12, double& s22) {
+#pragma clang fp contract(fast)
+  double RC[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double r0 = R[r * 3], r1 = R[r * 3 + 1], r2 = R[r * 3 + 2];
+    RC[r * 3 + 0] = r0 * c1[0] + r1 * c1[1] + r2 * c1[2];
+    RC[r * 3 + 1] = r0 * c1[1] + r1 * c1[3] + r2 * c1[4];
+    RC[r * 3 + 2] = r0 * c1[2] + r1 * c1[4] + r2 * c1[5];
+  }
+  s00 = RC[0] * R[0] + RC[1] * R[1] + RC[2] * R[2] + c2[0];
+  s01 = RC[0] * R[3] + RC[1] * R[4] + RC[2] * R[5] + c2[1];
+  s02 = RC[0] * R[6] + RC[1] * R[7] + RC[2] * R[8] + c2[2];
+  s11 = RC[3] * R[3] + RC[4] * R[4] + RC[5] * R[5] + c2[3];
+  s12 = RC[3] * R[6] + RC[4] * R[7] + RC[5] * R[8] + c2[4];
+  s22 = RC[6] * R[6] + RC[7] * R[7] + RC[8] * R[8] + c2[5];
+}
+
+// 1 / x for a positive, normal x: hardware estimate and two Newton steps (an ulp or two off the
+// rounded quotient, a third of the instructions of the IEEE division sequence)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// COMPACT: every cloud of the launch carries flagged normals and 32-byte records (covariances
+// from normals); otherwise stored covariances and 64-byte records (covariances from k-NN)
+template <bool COMPACT>
 __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
     const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
     const PairState* __restrict__ st, const int4* __restrict__ bmap, double corr_dist2,
@@ -74,7 +113,20 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
     }
 #pragma unroll
   for (int i = 0; i < 12; ++i) Th[i] = (double)S.T[i];  // rows 0..2 of the 4x4, row-major
+  // R R^T + 1 (R comes from a float matrix and is orthogonal to 1e-7 only, so this is not 2)
+  const double G[6] = {R[0] * R[0] + R[1] * R[1] + R[2] * R[2] + 1.0,
+                       R[0] * R[3] + R[1] * R[4] + R[2] * R[5],
+                       R[0] * R[6] + R[1] * R[7] + R[2] * R[8],
+                       R[3] * R[3] + R[4] * R[4] + R[5] * R[5] + 1.0,
+                       R[3] * R[6] + R[4] * R[7] + R[5] * R[8],
+                       R[6] * R[6] + R[7] * R[7] + R[8] * R[8] + 1.0};
 
+  const float4* __restrict__ const out = P.out;
+  const nnkey_t* __restrict__ const keys = P.keys;
+  const float4* __restrict__ const s_cnrm = SC.cnrm;
+  const double* __restrict__ const s_cov = SC.cov;
+  const float4* __restrict__ const t_rec = TC.rec;
+  const double* __restrict__ const t_cov = TC.cov;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* const sa = stage[wave];
   double* const sb = sa + RM_ROWS_A * RM_STR;
@@ -84,6 +136,9 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
   const double* const pa = sa + orow * RM_STR + ok;
   const double* const pb = sb + ocol * RM_STR + ok;
   red_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  double av[RM_ROWS_A];
+#pragma unroll
+  for (int r = 0; r < RM_ROWS_A; ++r) av[r] = 0.0;
 
   const int n = P.n_src;
   const int per = (n + bm.z - 1) / bm.z;
@@ -97,45 +152,69 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
 #pragma unroll
    for (int r = 0; r < AHEAD; ++r) {
      const int i = gbase + r * RED_THREADS + lane;
-     kahead[r] = i < i1 ? P.keys[i] : NNKEY_NONE;
+     kahead[r] = i < i1 ? keys[i] : NNKEY_NONE;
    }
 #pragma unroll
    for (int r = 0; r < AHEAD; ++r) {
     const int base = gbase + r * RED_THREADS;
     if (base >= i1) break;
     const int i = base + lane;
-    double av[RM_ROWS_A], bv[RM_ROWS_B];
-#pragma unroll
-    for (int r = 0; r < RM_ROWS_A; ++r) av[r] = 0.0;
+    // a lane without a correspondence contributes b = 0; its a keeps the (finite) values of an
+    // earlier round, whose products with zero add nothing
+    double bv[RM_ROWS_B];
 #pragma unroll
     for (int c = 0; c < RM_ROWS_B; ++c) bv[c] = 0.0;
     const nnkey_t key = kahead[r];
     const float d2 = __uint_as_float((unsigned)(key >> 32));
     if (key != NNKEY_NONE && (double)d2 < corr_dist2) {  // gicp.hpp:483
       const int j = (int)(key & 0xFFFFFFFFu);
-      const float4 pf = P.out[i];
-      // the matched target's point and covariance sit in one 64-byte record: one cache line
-      const float4* const tr = TC.rec + 4 * (size_t)j;
-      const float4 qf = tr[0];
-      const double* c1 = SC.cov + 6 * (size_t)i;
-      const double* c2 = reinterpret_cast<const double*>(tr + 1);
-      const double a00 = c1[0], a01 = c1[1], a02 = c1[2], a11 = c1[3], a12 = c1[4], a22 = c1[5];
-      // RC = R * C1
-      double RC[9];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double r0 = R[r * 3], r1 = R[r * 3 + 1], r2 = R[r * 3 + 2];
-        RC[r * 3 + 0] = r0 * a00 + r1 * a01 + r2 * a02;
-        RC[r * 3 + 1] = r0 * a01 + r1 * a11 + r2 * a12;
-        RC[r * 3 + 2] = r0 * a02 + r1 * a12 + r2 * a22;
+      const float4 pf = out[i];
+      float4 qf;
+      double s00, s01, s02, s11, s12, s22;  // S = R C1 R^T + C2 (symmetric)
+      if constexpr (COMPACT) {
+        // Compact clouds keep the stored normal instead of the six doubles: 16 bytes read per
+        // source point instead of 48, one 32-byte record gathered per match instead of 64, all
+        // four loads issued together.  With C = 1 - k n n^T (k = 0.999 / |n|^2, see
+        // cov_of_regular_normal) the sum is S = (R R^T + 1) - k1 (R n1)(R n1)^T - k2 n2 n2^T:
+        // the same quantity as R C1 R^T + C2 whatever R is, in a third of the operations.  The
+        // rare points whose normal falls into one of the reference's special branches carry a
+        // flag; a wave that holds one redoes those lanes from the stored matrices (wave-uniform
+        // test, so the common path has no branch between its loads and their use).
+        const float4 n1 = s_cnrm[i];
+        const float4* const tr = t_rec + 2 * (size_t)j;
+        qf = tr[0];
+        const float4 n2 = tr[1];
+        const double n1x = n1.x, n1y = n1.y, n1z = n1.z, n2x = n2.x, n2y = n2.y, n2z = n2.z;
+        const double k1 = 0.999 * fast_rcp(n1x * n1x + n1y * n1y + n1z * n1z);
+        const double k2 = 0.999 * fast_rcp(n2x * n2x + n2y * n2y + n2z * n2z);
+        const double m0 = R[0] * n1x + R[1] * n1y + R[2] * n1z;
+        const double m1 = R[3] * n1x + R[4] * n1y + R[5] * n1z;
+        const double m2 = R[6] * n1x + R[7] * n1y + R[8] * n1z;
+        const double u0 = k1 * m0, u1 = k1 * m1, u2 = k1 * m2;
+        const double v0 = k2 * n2x, v1 = k2 * n2y, v2 = k2 * n2z;
+        s00 = (G[0] - u0 * m0) - v0 * n2x;
+        s01 = (G[1] - u0 * m1) - v0 * n2y;
+        s02 = (G[2] - u0 * m2) - v0 * n2z;
+        s11 = (G[3] - u1 * m1) - v1 * n2y;
+        s12 = (G[4] - u1 * m2) - v1 * n2z;
+        s22 = (G[5] - u2 * m2) - v2 * n2z;
+        if (__builtin_expect(__ballot(n1.w != 0.f || n2.w != 0.f) != 0, 0)) {
+          if (n1.w != 0.f || n2.w != 0.f) {
+            double c1[6], c2[6];
+            if (n1.w != 0.f) load_cov6(s_cov + 6 * (size_t)i, c1); else cov_of_regular_normal(n1, c1);
+            if (n2.w != 0.f) load_cov6(t_cov + 6 * (size_t)j, c2); else cov_of_regular_normal(n2, c2);
+            sandwich(R, c1, c2, s00, s01, s02, s11, s12, s22);
+          }
+        }
+      } else {
+        // the matched target's point and covariance sit in one 64-byte record: one cache line
+        const float4* const tr = t_rec + 4 * (size_t)j;
+        qf = tr[0];
+        double c1[6], c2[6];
+        load_cov6(s_cov + 6 * (size_t)i, c1);
+        load_cov6(reinterpret_cast<const double*>(tr + 1), c2);
+        sandwich(R, c1, c2, s00, s01, s02, s11, s12, s22);
       }
-      // S = RC * R^T + C2 (symmetric)
-      const double s00 = RC[0] * R[0] + RC[1] * R[1] + RC[2] * R[2] + c2[0];
-      const double s01 = RC[0] * R[3] + RC[1] * R[4] + RC[2] * R[5] + c2[1];
-      const double s02 = RC[0] * R[6] + RC[1] * R[7] + RC[2] * R[8] + c2[2];
-      const double s11 = RC[3] * R[3] + RC[4] * R[4] + RC[5] * R[5] + c2[3];
-      const double s12 = RC[3] * R[6] + RC[4] * R[7] + RC[5] * R[8] + c2[4];
-      const double s22 = RC[6] * R[6] + RC[7] * R[7] + RC[8] * R[8] + c2[5];
       // M = S^-1 by cofactors (Eigen's 3x3 inverse, gicp.hpp:493)
       const double k00 = s11 * s22 - s12 * s12;
       const double k01 = s02 * s12 - s01 * s22;
@@ -210,10 +289,14 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
 
 hipError_t launch_gicp_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
                               const int4* bmap, int n_blocks, double corr_dist2, double* partials,
-                              hipStream_t stream) {
+                              bool compact, hipStream_t stream) {
   if (n_blocks <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gicp_reduce_kernel, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
-                     pairs, st, bmap, corr_dist2, partials);
+  if (compact)
+    hipLaunchKernelGGL(gicp_reduce_kernel<true>, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
+                       pairs, st, bmap, corr_dist2, partials);
+  else
+    hipLaunchKernelGGL(gicp_reduce_kernel<false>, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
+                       pairs, st, bmap, corr_dist2, partials);
   return hipGetLastError();
 }
 

@@ -11,8 +11,8 @@
 //     that keys every point with (range, coordinate along the range's longest axis) and one
 //     radix sort over all points of the batch; ranges split at tile boundaries (median split),
 //     so after the last level every run of SI_TILE points is a compact tile,
-//   * tiles / boxes / query order (index_fill_kernel), covariances from the normals and the
-//     64-byte records in one fused pass, the NormalizePCloud constants of all keyframes in one
+//   * tiles / boxes / query order (index_fill_kernel), covariances from the normals, flagged
+//     normals and the 32-byte records in one fused pass, the NormalizePCloud constants of all keyframes in one
 //     launch (one wave per keyframe, sequential float sums by contract),
 //   * no stream synchronisation: the constants land in pinned host memory and are picked up by
 //     the next call that needs them (lgicp_submit, lgicp_wait_registered).
@@ -34,7 +34,8 @@ struct RegKf {  // one keyframe of a registration batch
   const float4* xyz;  // n_pad points
   const float4* nrm;  // n normals
   double* cov;        // n x 6 (null: index only)
-  float4* rec;        // n x 4
+  float4* rec;        // n x 2: point, flagged normal (CloudDev::rec, compact form)
+  float4* cnrm;       // n: flagged normal
   int* order;         // n: final visiting order (local indices)
   int pos0;           // first global position
   int n;
@@ -177,8 +178,9 @@ __global__ __launch_bounds__(256) void kd_order_out_kernel(const RegKf* __restri
   K.order[pos - K.pos0] = ids[pos];
 }
 
-// covariance from the stored normal (gicp_utils.h:28-62, all in double) and the 64-byte record
-// (point + covariance) in one pass; arithmetic identical to cov_from_normals_kernel
+// covariance from the stored normal (gicp_utils.h:28-62, all in double; arithmetic identical to
+// cov_from_normals_kernel), the flagged normal and the 32-byte record (point + flagged normal) the
+// reduction reads instead of the covariance wherever the closed form holds, in one pass
 __global__ __launch_bounds__(256) void derive_kernel(const RegKf* __restrict__ kfs) {
   const RegKf& K = kfs[blockIdx.y];
   if (!K.cov) return;
@@ -215,10 +217,11 @@ __global__ __launch_bounds__(256) void derive_kernel(const RegKf* __restrict__ k
     c[5] = 0.001 * nz * nz + v1z * v1z + v2z * v2z;
     double2* co = reinterpret_cast<double2*>(K.cov + 6 * (size_t)i);
     co[0] = make_double2(c[0], c[1]), co[1] = make_double2(c[2], c[3]), co[2] = make_double2(c[4], c[5]);
-    float4* r = K.rec + 4 * (size_t)i;
+    const float4 cn = make_float4(nf.x, nf.y, nf.z, normal_is_special(nf));
+    K.cnrm[i] = cn;
+    float4* r = K.rec + 2 * (size_t)i;
     r[0] = K.xyz[i];
-    double2* rc = reinterpret_cast<double2*>(r + 1);
-    rc[0] = make_double2(c[0], c[1]), rc[1] = make_double2(c[2], c[3]), rc[2] = make_double2(c[4], c[5]);
+    r[1] = cn;
   }
 }
 
@@ -294,7 +297,7 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
 
   // ---- layout: [uploaded: xyz, nrm of every keyframe] [derived arrays of every keyframe] --------
   struct Lay {
-    size_t xyz, nrm, order, sxyz, tmin, tmax, qorder, cov, rec, nrm_x;
+    size_t xyz, nrm, order, sxyz, tmin, tmax, qorder, cov, rec, cnrm, nrm_x;
     int n, n_pad, n_tiles, n_q, nf;
     bool missing;
   };
@@ -321,10 +324,11 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
     L.tmin = bytes, bytes += align256(sizeof(float4) * t);
     L.tmax = bytes, bytes += align256(sizeof(float4) * t);
     L.qorder = bytes, bytes += align256(sizeof(int) * (size_t)std::max(L.n_q, 64));
-    L.cov = L.rec = L.nrm_x = 0;
+    L.cov = L.rec = L.cnrm = L.nrm_x = 0;
     if (derive) {
       L.cov = bytes, bytes += align256(sizeof(double) * 6 * n);
-      L.rec = bytes, bytes += align256(sizeof(float4) * 4 * n);
+      L.rec = bytes, bytes += align256(sizeof(float4) * 2 * n);
+      L.cnrm = bytes, bytes += align256(sizeof(float4) * n);
     }
   }
 
@@ -388,10 +392,11 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
     if (derive) {
       kf.d_cov = reinterpret_cast<double*>(base + L.cov);
       kf.d_rec = reinterpret_cast<float4*>(base + L.rec);
+      kf.d_cnrm = reinterpret_cast<float4*>(base + L.cnrm);
       kf.d_nrm_x = L.missing ? reinterpret_cast<float4*>(base + L.nrm_x) : kf.d_nrm;
     }
     RegKf& g = h_kfs[k];
-    g.xyz = kf.d_xyz, g.nrm = kf.d_nrm, g.cov = kf.d_cov, g.rec = kf.d_rec, g.order = kf.d_order;
+    g.xyz = kf.d_xyz, g.nrm = kf.d_nrm, g.cov = kf.d_cov, g.rec = kf.d_rec, g.cnrm = kf.d_cnrm, g.order = kf.d_order;
     g.pos0 = pos, g.n = L.n, g.nf = L.nf, g.tile_base = tile_base;
     pos += L.n;
     tile_base += L.n_tiles + 1;

@@ -417,7 +417,7 @@ int plan_cloud(lgicp_ctx* ctx, BatchPlan& bp, uint64_t key, bool accumulate) {
   cp.n = ctx->scans.at(key).n;
   for (auto& s : cp.segs) cp.n += ctx->scans.at(s.first).n;
   cp.n_pad = std::max(NN_TILE, round_up(cp.n, NN_TILE));
-  if (acc || ctx->cfg.covariance_from_knn) bp.bytes += (size_t)cp.n * (48 + 64) + 512;  // covariances, records
+  if (acc || ctx->cfg.covariance_from_knn) bp.bytes += (size_t)cp.n * (48 + 64) + 1024;  // covariances, records (or flagged normals + compact records)
   if (acc) {
     bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 32 + 1024;  // xyz + normals (+ estimated)
     // spatial index: tile-ordered points, boxes, visiting order
@@ -471,7 +471,10 @@ void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t
     cd.n_pad = cp.n_pad;
     const bool own_cov = cp.accumulated || cfg.covariance_from_knn;
     cd.cov = own_cov ? ar.take<double>((size_t)cp.n * 6) : kf.d_cov;
-    cd.rec = own_cov ? ar.take<float4>((size_t)cp.n * 4) : kf.d_rec;
+    // covariances from normals: flagged normals and 32-byte records; from k-NN: 64-byte records
+    cd.compact = cfg.covariance_from_knn ? 0 : 1;
+    cd.rec = own_cov ? ar.take<float4>((size_t)cp.n * (cd.compact ? 2 : 4)) : kf.d_rec;
+    cd.cnrm = cd.compact ? (own_cov ? ar.take<float4>((size_t)cp.n) : kf.d_cnrm) : nullptr;
     max_cloud_n = std::max(max_cloud_n, cp.n);
     if (!cp.accumulated) {
       cd.xyz = kf.d_xyz;
@@ -530,6 +533,9 @@ void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t
       s.dst_nrm = nrm;
       s.src_cov = acc_cov ? kf.d_cov : nullptr;
       s.dst_cov = acc_cov;
+      s.src_cnrm = acc_cov ? kf.d_cnrm : nullptr;
+      s.dst_cnrm = acc_cov ? const_cast<float4*>(cd.cnrm) : nullptr;
+      s.dst_rec = acc_cov ? const_cast<float4*>(cd.rec) : nullptr;
       s.n = kf.n;
       s.identity = 1;
       h_segs.push_back(s);
@@ -544,6 +550,9 @@ void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t
         s.dst_nrm = nrm + off;
         s.src_cov = acc_cov ? nk.d_cov : nullptr;
         s.dst_cov = acc_cov ? acc_cov + 6 * (size_t)off : nullptr;
+        s.src_cnrm = acc_cov ? nk.d_cnrm : nullptr;
+        s.dst_cnrm = acc_cov ? const_cast<float4*>(cd.cnrm) + off : nullptr;
+        s.dst_rec = acc_cov ? const_cast<float4*>(cd.rec) + 2 * (size_t)off : nullptr;
         s.n = nk.n;
         s.identity = 0;
         for (int a = 0; a < 3; ++a) {
@@ -1061,8 +1070,9 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   }
   // covariances from normals and the NormalizePCloud constants were derived when the keyframes
   // were registered; accumulated clouds received their members' covariances in launch_assemble
-  for (int c = 0; c < n_clouds; ++c)
-    if (bp.clouds[c].accumulated || cfg.covariance_from_knn)
+  // (with their flagged normals and 32-byte records); 64-byte records go with k-NN covariances
+  if (cfg.covariance_from_knn)
+    for (int c = 0; c < n_clouds; ++c)
       HIP_TRY(ctx, launch_pack_records(h_clouds[c].xyz, h_clouds[c].cov, h_clouds[c].n,
                                        const_cast<float4*>(h_clouds[c].rec), st));
 
@@ -1172,7 +1182,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     HIP_TRY(ctx, hipEventRecord(b, st));
     HIP_TRY(ctx, launch_gicp_reduce(d_clouds, d_pairs, d_state,
                                     d_bmap_red, (int)h_bmap_red.size(), sp.corr_dist2,
-                                    W->d_partials.p, st));
+                                    W->d_partials.p, !cfg.covariance_from_knn, st));
     HIP_TRY(ctx, hipEventRecord(c, st));
     HIP_TRY(ctx, launch_gicp_solve(d_pairs, d_state, n_pairs, d_ints,
                                    W->d_partials.p, sp, d_done, st));

@@ -40,7 +40,14 @@ struct CloudDev {
   const float4* nrm_x;  // lamp_utils::ExtractNormals of the cloud: nrm, or k-NN normals when the
                         // first stored normal is all zero (PointCloudUtils.cc:17-35)
   const double* cov;  // n x 6: c00 c01 c02 c11 c12 c22
-  const float4* rec;  // n records of 64 bytes: the point (x, y, z, 1), then the same six doubles
+  const float4* rec;  // what the reduction gathers per match.  compact == 0: n records of 64 bytes,
+                      // the point (x, y, z, 1), then the same six doubles.  compact == 1: n records
+                      // of 32 bytes, the point (x, y, z, 1), then cnrm's entry of the point
+  const float4* cnrm; // compact == 1: the stored normal (x, y, z) and a flag w: 0 = the covariance
+                      // of the point is 1 - 0.999 n n^T / |n|^2 to rounding (rebuilt where it is
+                      // needed), 1 = one of the reference's special cases (zero or non-finite
+                      // normal, clamped z): take cov
+  int compact;
   int n;
   int n_pad;
   // spatial index (spatial_index.hip)
@@ -56,6 +63,35 @@ struct CloudDev {
   float centroid[3];
   float factor;
 };
+
+// Covariance of a point from its stored normal when none of the special branches of
+// PCLTwoPlaneVectorsFromNormal (lamp_utils/include/lamp_utils/gicp_utils.h:28-48) applies: the
+// reference builds C = 0.001 n n^T + v1 v1^T + v2 v2^T from the normalised normal n and two unit
+// vectors that complete it to an orthonormal basis, i.e. C = 1 - 0.999 n n^T; written with the
+// unnormalised normal, C = 1 - (0.999 / |n|^2) n n^T, which costs one division and agrees with the
+// reference's construction to 6e-16 absolute (both carry a few roundings of entries <= 1).
+__device__ __forceinline__ void cov_of_regular_normal(const float4 nf, double c[6]) {
+  const double nx = nf.x, ny = nf.y, nz = nf.z;
+  const double k = 0.999 / (nx * nx + ny * ny + nz * nz);
+  const double kx = k * nx, ky = k * ny, kz = k * nz;
+  c[0] = 1.0 - kx * nx;
+  c[1] = -(kx * ny);
+  c[2] = -(kx * nz);
+  c[3] = 1.0 - ky * ny;
+  c[4] = -(ky * nz);
+  c[5] = 1.0 - kz * nz;
+}
+
+// 1 when the reference's construction takes a special branch for this normal (zero or non-finite
+// length: nothing to normalise; z component clamped to 1e-7 before or after normalisation): the
+// closed form above does not describe those, their covariance is read from memory instead.
+__device__ __forceinline__ float normal_is_special(const float4 nf) {
+  const double nx = nf.x, ny = nf.y, nz = nf.z;
+  const double z = nx * nx + ny * ny + nz * nz;
+  if (!(z > 0) || !(z < 1.0e300)) return 1.f;
+  const double nzn = nz / sqrt(z);
+  return (fabs(nz) < 0.0000001 || fabs(nzn) < 0.0000001) ? 1.f : 0.f;
+}
 
 struct PairDev {
   int src_cloud;    // accumulated source
@@ -114,6 +150,9 @@ struct SegmentDev {  // one keyframe appended to an accumulated cloud
   float4* dst_nrm;
   const double* src_cov;  // optional: the keyframe's covariances-from-normals, copied along
   double* dst_cov;
+  const float4* src_cnrm;  // with src_cov: the keyframe's flagged normals, copied along, and the
+  float4* dst_cnrm;        // 32-byte records (moved point + flagged normal) of the new cloud
+  float4* dst_rec;
   double T[12];  // row-major 3x4, applied in double then cast (transformPointCloud<double>)
   int n;
   int identity;  // 1: plain copy (the key's own scan)
@@ -162,9 +201,10 @@ hipError_t launch_keys_unpack(const nnkey_t* keys, int n, int32_t* idx, float* d
                               hipStream_t stream);
 
 // bmap entry: x = pair, y = chunk, z = number of chunks
+// compact: the clouds carry flagged normals and 32-byte records (CloudDev::compact == 1, all of them)
 hipError_t launch_gicp_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
                               const int4* bmap, int n_blocks, double corr_dist2, double* partials,
-                              hipStream_t stream);
+                              bool compact, hipStream_t stream);
 hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
                              const int* n_chunks, const double* partials, SolveParams sp,
                              int* n_done, hipStream_t stream);

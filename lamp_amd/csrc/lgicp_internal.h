@@ -56,7 +56,8 @@ struct Keyframe {
   // derived once at registration: covariances from the normals (gicp_utils.h:28-62) and the
   // NormalizePCloud constants (PointCloudUtils.cc:39-59); both depend on the keyframe alone
   double* d_cov = nullptr;  // n x 6
-  float4* d_rec = nullptr;  // n x 64 bytes: point + covariance, what the reduction gathers per match
+  float4* d_rec = nullptr;  // n x 32 bytes: point + flagged normal, what the reduction gathers per match
+  float4* d_cnrm = nullptr; // n: the stored normal, w = 1 where the covariance has to be read from d_cov
   // lamp_utils::ExtractNormals of the keyframe: d_nrm itself, or k-NN normals (own buffer) when
   // the first stored normal is all zero
   float4* d_nrm_x = nullptr;
@@ -69,7 +70,7 @@ struct Keyframe {
   std::shared_ptr<CloudFeatures> features;
   void free_device() {
     block.reset();
-    d_xyz = d_nrm = d_sxyz = d_tmin = d_tmax = d_nrm_x = d_rec = nullptr;
+    d_xyz = d_nrm = d_sxyz = d_tmin = d_tmax = d_nrm_x = d_rec = d_cnrm = nullptr;
     d_order = d_qorder = nullptr;
     d_cov = nullptr;
   }

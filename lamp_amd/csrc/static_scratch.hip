@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void static_nn_setup_kernel(
     CloudDev* const c = reinterpret_cast<CloudDev*>(base + kOffClouds);
     CloudDev z;
     z.xyz = nullptr, z.nrm = nullptr, z.nrm_x = nullptr, z.cov = nullptr, z.rec = nullptr;
+    z.cnrm = nullptr, z.compact = 0;
     z.n = 0, z.n_pad = 0;
     z.sxyz = nullptr, z.tmin = nullptr, z.tmax = nullptr, z.qorder = nullptr;
     z.n_tiles = 0, z.n_q = 0;
