@@ -208,8 +208,8 @@ def make_config(capi, args, local_rank, slots=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=80)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
     ap.add_argument("--batches", type=int, default=0,
@@ -231,6 +231,9 @@ def main():
                     help="initialise torch.distributed and run the result gather even with one rank")
     ap.add_argument("--slots", type=int, default=0,
                     help="parts of a submit in flight at once (0 = the library's default)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="submits in flight at once, each from its own host thread "
+                         "(lgicp_set_submit_lanes; 0 = 4 for the GICP-only configurations, 1 for C4)")
     ap.add_argument("--exhaustive", action="store_true",
                     help="use the exhaustive 1-NN kernel instead of the pruned one")
     args = ap.parse_args()
@@ -282,6 +285,12 @@ def main():
     total_pairs_per_batch = len(works[0].pairs) if strong else len(works[0].pairs) * world
 
     ctx = capi.Context(make_config(capi, args, local_rank, args.slots))
+    # Steps overlap: the last outer iterations of a batch (a handful of pairs, latency-bound) run
+    # beside the full-size launches of the next ones.  Feature-based initialisations take the whole
+    # context per submit, so C4 stays at one.
+    in_flight = args.in_flight or (1 if args.config == "C4" else 4)
+    if in_flight > 1:
+        in_flight = ctx.set_submit_lanes(in_flight)
 
     def register(c, w, keys):
         t0 = time.perf_counter()
@@ -295,7 +304,9 @@ def main():
     for w, keys in zip(works, key_lists):     # keyframes + poses resident in HBM before timing
         reg_s += register(ctx, w, keys)
         reg_kf += len(keys)
-    packed = [ctx.pack_candidates(c) for c in cand_lists]
+    # one set of candidate / result arrays per submit in flight: step i uses set i mod in_flight
+    packed_sets = [[ctx.pack_candidates(c) for c in cand_lists] for _ in range(in_flight)]
+    packed = packed_sets[0]
     progress(f"{reg_kf} keyframes registered in {reg_s:.3f} s")
 
     gatherer = None
@@ -315,14 +326,65 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    def gather(i, out):
+        if dist is not None:
+            import torch
+            gatherer.gather(pack_results(out, len(cand_lists[i % n_batches])))   # rank 0 ends with every record
+            torch.cuda.synchronize()
+
     def step(i, c=None, pk=None):
         b = i % n_batches
         out = (c or ctx).submit_packed((pk or packed)[b])   # blocking: returns after the device work
-        if dist is not None and c is None:
-            import torch
-            gatherer.gather(pack_results(out, len(cand_lists[b])))   # rank 0 ends with every record
-            torch.cuda.synchronize()
+        if c is None:
+            gather(i, out)
         return out
+
+    def collect_overlapped(n_steps, first, depth):
+        """`depth` steps in flight, each submitted by a pool thread; results are taken (and, with
+        several ranks, gathered) in step order by this thread.  Stage times are what lgicp_get_stats
+        reports as "last submit" when a step returns: with submits side by side that is now and
+        then the neighbour's, so the sums are indicative; the launch and distance counters are
+        exact differences over the region."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        acc = dict(nn_ms=0.0, nn_launches=0.0, nn_evals=0.0, nn_exec=0.0, red_ms=0.0,
+                   red_launches=0.0, red_points=0.0, red_inliers=0.0, cycle_exits=0.0,
+                   clique_ms=0.0, clique_bytes=0.0, clique_launches=0.0,
+                   hindex_ms=0.0, hindex_bytes=0.0, hindex_launches=0.0)
+        stage = dict(nn=0.0, reduce=0.0, solve=0.0, cov=0.0, post=0.0, total=0.0)
+        res = []
+        s_begin = ctx.stats()
+
+        def one(i):
+            out = ctx.submit_packed(packed_sets[i % depth][i % n_batches])
+            return i, out, ctx.stats()
+
+        def finish(fut):
+            i, out, s1 = fut.result()
+            gather(i, out)
+            res.append(out)
+            acc["nn_ms"] += s1.nn_ms
+            acc["nn_exec"] += s1.nn_executed_evals
+            acc["red_ms"] += s1.reduce_ms
+            acc["red_launches"] += s1.reduce_launches
+            acc["red_points"] += s1.reduce_points
+            acc["red_inliers"] += s1.reduce_inliers
+            acc["cycle_exits"] += s1.cycle_exits
+            for k in stage:
+                stage[k] += getattr(s1, k + "_ms")
+
+        with ThreadPoolExecutor(depth) as pool:
+            pending = deque()
+            for i in range(first, first + n_steps):
+                if len(pending) == depth:
+                    finish(pending.popleft())
+                pending.append(pool.submit(one, i))
+            while pending:
+                finish(pending.popleft())
+        s_end = ctx.stats()
+        acc["nn_launches"] = s_end.nn_launches - s_begin.nn_launches
+        acc["nn_evals"] = s_end.nn_distance_evals - s_begin.nn_distance_evals
+        return acc, stage, res
 
     def collect(c, n_steps, first, pk=None):
         acc = dict(nn_ms=0.0, nn_launches=0.0, nn_evals=0.0, nn_exec=0.0, red_ms=0.0,
@@ -360,9 +422,23 @@ def main():
     for i in range(args.warmup):
         step(i)
         progress(f"warm-up {i + 1}/{args.warmup}")
+    serial = None
+    if in_flight > 1:
+        # every set of arrays and every lane's buffers sized before the timed region; and, for the
+        # record, the same steps one at a time (each submit on one lane's share of the context)
+        collect_overlapped(2 * in_flight, 0, in_flight)
+        n_ser = max(n_batches, min(args.steps, 8))
+        barrier()
+        t_ser = time.perf_counter()
+        collect(ctx, n_ser, 0)
+        barrier()
+        serial = (time.perf_counter() - t_ser) / n_ser
     barrier()
     t0 = time.perf_counter()
-    acc, stage, results = collect(ctx, args.steps, args.warmup)
+    if in_flight > 1:
+        acc, stage, results = collect_overlapped(args.steps, args.warmup, in_flight)
+    else:
+        acc, stage, results = collect(ctx, args.steps, args.warmup)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -469,7 +545,8 @@ def main():
                 "workload": (f"{args.config}: {len(w0.pairs)} candidate pairs "
                              f"{'in all, cut over the ranks' if strong else 'per GPU and step'}, "
                              f"{w0.n_points}-pt VLP-16-like keyframes ({w0.n_keyframes} distinct per "
-                             f"batch, steps rotate through {n_batches} batch(es)), GICP base-station "
+                             f"batch, steps rotate through {n_batches} batch(es), {in_flight} step(s) in "
+                             f"flight at once), GICP base-station "
                              f"parameters (corr_dist 0.5, <=200 outer iterations, tf_epsilon 1e-10), "
                              + (("SAC-IA" if args.c4_init == "sac" else "TEASER++")
                                 + " initialisation from FPFH matches at Harris keypoints "
@@ -494,6 +571,12 @@ def main():
                                 (f"every one of {world} GPUs runs its own batches, RCCL gather to rank 0"
                                  if world > 1 else "single GPU")),
                 "stage_ms_per_step": {k: v / args.steps for k, v in stage.items()},
+                "submits_in_flight": in_flight,
+                "one_submit_at_a_time": (None if serial is None else
+                                         {"ms_per_step": 1e3 * serial,
+                                          "value": total_pairs_per_batch / serial,
+                                          "what": "the same steps submitted one after the other (each on "
+                                                  "one lane's share of the context's streams)"}),
                 "registration": {"keyframes": reg_kf, "seconds": reg_s,
                                  "what": "lgicp_add_keyframes + lgicp_wait_registered per batch: upload, "
                                          "k-d index, covariances, records, NormalizePCloud constants"},

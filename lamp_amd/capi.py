@@ -19,7 +19,8 @@ EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_
            "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh",
            "lgicp_harris_keypoints", "lgicp_sac_initial_alignment",
            "lgicp_teaser_initial_alignment", "lgicp_compute_normals", "lgicp_icp_observability",
-           "lgicp_voxel_grid", "lgicp_random_sample", "lgicp_nn_search_static", "lgicp_add_keyframes", "lgicp_wait_registered"]
+           "lgicp_voxel_grid", "lgicp_random_sample", "lgicp_nn_search_static", "lgicp_add_keyframes", "lgicp_wait_registered",
+           "lgicp_set_submit_lanes"]
 
 
 class Config(C.Structure):
@@ -101,6 +102,7 @@ def lib():
         L.lgicp_has_pose.argtypes = [C.c_void_p, C.c_uint64]
         L.lgicp_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lgicp_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.lgicp_set_submit_lanes.argtypes = [C.c_void_p, C.c_int]
         L.lgicp_nn_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lgicp_covariances_from_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -233,6 +235,11 @@ class Context:
         arr, n, out = packed
         self._check(lib().lgicp_submit(self._h, arr, n, out))
         return out
+
+    def set_submit_lanes(self, lanes):
+        """lgicp_set_submit_lanes: submits of different threads that may run side by side (1 or 2);
+        returns the number in effect."""
+        return self._check(lib().lgicp_set_submit_lanes(self._h, lanes))
 
     def submit(self, candidates):
         """candidates: list of (key_from, key_to[, pose_from(q,t), pose_to(q,t)])"""

@@ -218,6 +218,9 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
         const float hy = __builtin_fmaxf(0.f, __builtin_fmaxf(y0 - y, y - y1));
         const float hz = __builtin_fmaxf(0.f, __builtin_fmaxf(z0 - z, z - z1));
         const float gl = (hx * hx + hy * hy) + hz * hz;
+#ifdef NNP_COUNT_CONSIDERED  // diagnostics build: the counter reports tiles tested, not tiles walked
+        ++visited;
+#endif
         if (__ballot(need && gl <= bestd && gl <= cap) == 0) {
           ruled = __builtin_fminf(ruled, gl);
           continue;
@@ -247,7 +250,9 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
           bestd = lower ? m : bestd;
           bgrp = lower ? tile * (SI_TILE / GROUP) + g : bgrp;
         }
+#ifndef NNP_COUNT_CONSIDERED
         ++visited;
+#endif
       }
     }
     worst = wave_max_nonneg(need ? bestd : 0.f);

@@ -269,7 +269,7 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
   ctx->feature_scratch = std::shared_ptr<FeatureScratch>(new FeatureScratch[FEATURE_LANES],
                                                          std::default_delete<FeatureScratch[]>());
   ctx->sac_lanes = std::shared_ptr<SacLane>(new SacLane[FEATURE_LANES], std::default_delete<SacLane[]>());
-  ctx->helpers.start(ctx->n_slots - 1);
+  ctx->helpers[0].start(ctx->n_slots - 1);
   *out = ctx;
   return LGICP_OK;
 }
@@ -277,7 +277,7 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
 void lgicp_destroy(lgicp_ctx* ctx) {
   free_parked_device_memory();
   if (!ctx) return;
-  ctx->helpers.shutdown();
+  for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->helpers[l].shutdown();
   (void)hipSetDevice(ctx->cfg.device);
   for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
   for (auto& kv : ctx->scans) kv.second.free_device();
@@ -295,9 +295,63 @@ const char* lgicp_last_error(const lgicp_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
-int lgicp_add_keyframes(lgicp_ctx* ctx, size_t count, const uint64_t* keys, const float* const* xyz,
-                        const float* const* normals, const size_t* n_points, size_t stride_bytes) {
-  if (!ctx) return LGICP_E_INVALID;
+}  // extern "C"
+
+namespace {
+
+// Holds every lane of the context: nothing of it is in flight while this exists, and no submit
+// starts.  Outgrown device buffers parked by earlier submits are freed on the way in.
+struct AllLanes {
+  lgicp_ctx* ctx;
+  explicit AllLanes(lgicp_ctx* c) : ctx(c) {
+    std::unique_lock<std::mutex> lk(ctx->lane_mu);
+    ctx->lane_cv.wait(lk, [&] {
+      for (int l = 0; l < ctx->n_lanes; ++l)
+        if (ctx->lane_busy[l]) return false;
+      return true;
+    });
+    for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->lane_busy[l] = true;
+    free_parked_device_memory();
+  }
+  ~AllLanes() {
+    {
+      std::lock_guard<std::mutex> lk(ctx->lane_mu);
+      for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->lane_busy[l] = false;
+    }
+    ctx->lane_cv.notify_all();
+  }
+};
+
+// One lane (or, with a single lane configured, the whole context)
+struct OneLane {
+  lgicp_ctx* ctx;
+  int lane = 0;
+  explicit OneLane(lgicp_ctx* c) : ctx(c) {
+    std::unique_lock<std::mutex> lk(ctx->lane_mu);
+    ctx->lane_cv.wait(lk, [&] {
+      for (int l = 0; l < ctx->n_lanes; ++l)
+        if (!ctx->lane_busy[l]) return true;
+      return false;
+    });
+    bool any_busy = false;
+    for (int l = 0; l < ctx->n_lanes; ++l) any_busy = any_busy || ctx->lane_busy[l];
+    // outgrown buffers may still be read by what another lane has in flight
+    if (!any_busy) free_parked_device_memory();
+    while (ctx->lane_busy[lane]) ++lane;
+    ctx->lane_busy[lane] = true;
+  }
+  ~OneLane() {
+    {
+      std::lock_guard<std::mutex> lk(ctx->lane_mu);
+      ctx->lane_busy[lane] = false;
+    }
+    ctx->lane_cv.notify_all();
+  }
+};
+
+// caller holds data_mu exclusively
+int add_keyframes_locked(lgicp_ctx* ctx, size_t count, const uint64_t* keys, const float* const* xyz,
+                         const float* const* normals, const size_t* n_points, size_t stride_bytes) {
   if (count && (!keys || !xyz || !n_points)) return fail(ctx, LGICP_E_INVALID, "null argument");
   if (stride_bytes < 12 || stride_bytes % 4) return fail(ctx, LGICP_E_INVALID, "bad stride");
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
@@ -336,6 +390,29 @@ int lgicp_add_keyframes(lgicp_ctx* ctx, size_t count, const uint64_t* keys, cons
   return (int)in.size();
 }
 
+}  // namespace
+
+extern "C" {
+
+int lgicp_add_keyframes(lgicp_ctx* ctx, size_t count, const uint64_t* keys, const float* const* xyz,
+                        const float* const* normals, const size_t* n_points, size_t stride_bytes) {
+  if (!ctx) return LGICP_E_INVALID;
+  std::unique_lock<std::shared_mutex> data(ctx->data_mu);  // waits for submits in flight
+  return add_keyframes_locked(ctx, count, keys, xyz, normals, n_points, stride_bytes);
+}
+
+int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes) {
+  if (!ctx) return LGICP_E_INVALID;
+  if (lanes < 1) return fail(ctx, LGICP_E_INVALID, "lanes must be >= 1");
+  std::unique_lock<std::shared_mutex> data(ctx->data_mu);
+  AllLanes all(ctx);
+  lanes = std::min(lanes, std::min<int>(lgicp_ctx::MAX_LANES, ctx->n_slots));
+  for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->helpers[l].shutdown();
+  ctx->n_lanes = lanes;
+  for (int l = 0; l < lanes; ++l) ctx->helpers[l].start(ctx->n_slots / lanes - 1);
+  return lanes;
+}
+
 int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const float* normals,
                        size_t n, size_t stride_bytes) {
   return lgicp_add_keyframes(ctx, 1, &key, &xyz, normals ? &normals : nullptr, &n, stride_bytes);
@@ -343,6 +420,7 @@ int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const flo
 
 int lgicp_wait_registered(lgicp_ctx* ctx) {
   if (!ctx) return LGICP_E_INVALID;
+  std::unique_lock<std::shared_mutex> data(ctx->data_mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   const int rc = flush_registrations(ctx);
   if (rc != LGICP_OK) return rc;
@@ -352,20 +430,26 @@ int lgicp_wait_registered(lgicp_ctx* ctx) {
 
 int lgicp_add_pose(lgicp_ctx* ctx, uint64_t key, const double q[4], const double t[3]) {
   if (!ctx || !q || !t) return LGICP_E_INVALID;
+  std::unique_lock<std::shared_mutex> data(ctx->data_mu);
   if (ctx->poses.count(key)) return 0;  // first wins (IcpLoopComputation.cc:400-402)
   ctx->poses.emplace(key, hm::pose_from_quat(q, t));
   return 1;
 }
 
 int lgicp_has_keyframe(const lgicp_ctx* ctx, uint64_t key) {
-  return ctx && ctx->scans.count(key) ? 1 : 0;
+  if (!ctx) return 0;
+  std::shared_lock<std::shared_mutex> data(const_cast<lgicp_ctx*>(ctx)->data_mu);
+  return ctx->scans.count(key) ? 1 : 0;
 }
 int lgicp_has_pose(const lgicp_ctx* ctx, uint64_t key) {
-  return ctx && ctx->poses.count(key) ? 1 : 0;
+  if (!ctx) return 0;
+  std::shared_lock<std::shared_mutex> data(const_cast<lgicp_ctx*>(ctx)->data_mu);
+  return ctx->poses.count(key) ? 1 : 0;
 }
 
 int lgicp_get_stats(const lgicp_ctx* ctx, lgicp_stats* out) {
   if (!ctx || !out) return LGICP_E_INVALID;
+  std::lock_guard<std::mutex> lk(const_cast<lgicp_ctx*>(ctx)->stats_mu);
   *out = ctx->stats;
   return LGICP_OK;
 }
@@ -1390,13 +1474,28 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_submit).count());
   };
   HIP_TRY(ctx, hipSetDevice(cfg.device));
-  free_parked_device_memory();
+  // Keyframes and poses stay put for the duration (registration waits).  A submit runs on one lane
+  // of the context; the feature-based initialisations use buffers and streams the context has
+  // once and take all of it.
+  std::shared_lock<std::shared_mutex> data(ctx->data_mu);
+  const bool whole_context = cfg.init_method == LGICP_INIT_FEATURES ||
+                             cfg.init_method == LGICP_INIT_TEASERPP || ctx->n_lanes == 1;
+  std::unique_ptr<AllLanes> hold_all(whole_context ? new AllLanes(ctx) : nullptr);
+  std::unique_ptr<OneLane> hold_one(whole_context ? nullptr : new OneLane(ctx));
+  const int lane = hold_one ? hold_one->lane : 0;
+  const int lane_slots = hold_one ? ctx->n_slots / ctx->n_lanes : ctx->n_slots;
+  const int first_slot = lane * lane_slots;
+  // with several lanes configured lane 0's helpers serve fewer slots than a whole-context
+  // submit could use: it runs on the slots they cover
+  const int helper_slots = ctx->n_slots / ctx->n_lanes;
   {
     // keyframes registered since the last submit: their device work runs on the context's stream
+    std::lock_guard<std::mutex> fl(ctx->flush_mu);
     const int rc = flush_registrations(ctx);
     if (rc != LGICP_OK) return rc;
   }
-  reset_submit_stats(ctx->stats);
+  lgicp_stats sub;  // this submit's share of the statistics
+  std::memset(&sub, 0, sizeof(sub));
 
   // PerformAlignment's availability checks (IcpLoopComputation.cc:438-465)
   size_t n_valid = 0;
@@ -1407,7 +1506,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
     r.key_from = c.key_from;
     r.key_to = c.key_to;
     r.status = LGICP_PAIR_OK;
-    ctx->stats.pairs_submitted++;
+    sub.pairs_submitted++;
     if (!ctx->scans.count(c.key_from) || !ctx->scans.count(c.key_to))
       r.status = LGICP_PAIR_MISSING_SCAN;
     else if (!ctx->poses.count(c.key_from) || !ctx->poses.count(c.key_to))
@@ -1420,7 +1519,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
 
   // Several parts in flight at once when the submit is large enough (the feature-based
   // initialisations run their host stage on the context's own stream and stay serial).
-  int ways = ctx->n_slots;
+  int ways = std::min(lane_slots, helper_slots);
   if (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP) ways = 1;
   while (ways > 1 && n_valid < (size_t)32 * ways) --ways;
   const size_t max_pairs = std::min<size_t>(32767, (n_valid + ways - 1) / std::max(ways, 1));
@@ -1438,14 +1537,14 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
       rc_all = fail(ctx, LGICP_E_HIP, "hipSetDevice failed");
       return;
     }
-    BatchSlot* W = &ctx->slot[si];
+    BatchSlot* W = &ctx->slot[first_slot + si];
     // part k of a submit always runs in slot k mod ways: repeated submits of the same shape find
     // every slot's buffers already sized for their part
     for (size_t k = (size_t)si; k < plans.size() && rc_all == LGICP_OK; k += (size_t)ways) {
       std::memset(&W->stats, 0, sizeof(W->stats));
       const int rc = run_batch(ctx, W, plans[k], cand, out);
       std::lock_guard<std::mutex> lock(stats_mu);
-      merge_stats(ctx->stats, W->stats);
+      merge_stats(sub, W->stats);
       slot_total_ms[si] += W->stats.total_ms;
       if (rc != LGICP_OK) {
         rc_all = rc;
@@ -1453,7 +1552,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
       }
     }
   };
-  ctx->helpers.post(ways - 1, worker);
+  ctx->helpers[lane].post(ways - 1, worker);
   size_t i = 0;
   while (i < n) {
     BatchPlan bp;
@@ -1499,10 +1598,18 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   plans_ready.store(true, std::memory_order_release);
   worker(0);
   submit_mark("own part done");
-  ctx->helpers.wait();
+  ctx->helpers[lane].wait();
   submit_mark("all parts done");
   // device span of the submit: the slots overlap
-  ctx->stats.total_ms = *std::max_element(slot_total_ms, slot_total_ms + lgicp_ctx::MAX_SLOTS);
+  sub.total_ms = *std::max_element(slot_total_ms, slot_total_ms + lgicp_ctx::MAX_SLOTS);
+  {
+    // cumulative fields grow, the "last submit" fields become this submit's
+    std::lock_guard<std::mutex> lk(ctx->stats_mu);
+    reset_submit_stats(ctx->stats);
+    merge_stats(ctx->stats, sub);
+    ctx->stats.pairs_submitted += sub.pairs_submitted;
+    ctx->stats.total_ms = sub.total_ms;
+  }
   return rc_all;
 }
 
@@ -1515,11 +1622,14 @@ extern "C" int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* sr
   if (!ctx || !guess || !final_T) return fail(ctx, LGICP_E_INVALID, "null argument");
   if (n_src == 0 || n_tgt == 0) return fail(ctx, LGICP_E_INVALID, "empty cloud");
   const uint64_t ks = 0xFFFFFFF000000000ull, kt = 0xFFFFFFE000000000ull;
+  std::unique_lock<std::shared_mutex> data(ctx->data_mu);  // adds and removes two keyframes
+  AllLanes all(ctx);
   if (ctx->scans.count(ks) || ctx->scans.count(kt))
     return fail(ctx, LGICP_E_INVALID, "reserved keys in use");
-  int rc = lgicp_add_keyframe(ctx, ks, src_xyz, src_normals, n_src, 12);
+  if (hipSetDevice(ctx->cfg.device) != hipSuccess) return fail(ctx, LGICP_E_HIP, "hipSetDevice failed");
+  int rc = add_keyframes_locked(ctx, 1, &ks, &src_xyz, src_normals ? &src_normals : nullptr, &n_src, 12);
   if (rc < 0) return rc;
-  rc = lgicp_add_keyframe(ctx, kt, tgt_xyz, tgt_normals, n_tgt, 12);
+  rc = add_keyframes_locked(ctx, 1, &kt, &tgt_xyz, tgt_normals ? &tgt_normals : nullptr, &n_tgt, 12);
   if (rc >= 0) rc = flush_registrations(ctx);
   if (rc >= 0) {
     const double q[4] = {1, 0, 0, 0}, t[3] = {0, 0, 0};
@@ -1540,13 +1650,14 @@ extern "C" int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* sr
     std::memset(&c, 0, sizeof(c));
     lgicp_result r;
     std::memset(&r, 0, sizeof(r));
-    reset_submit_stats(ctx->stats);
     std::memset(&ctx->slot[0].stats, 0, sizeof(lgicp_stats));
-    rc = hipSetDevice(ctx->cfg.device) == hipSuccess ? run_batch(ctx, &ctx->slot[0], bp, &c, &r,
-                                                                 /*explicit_guess=*/true)
-                                                     : LGICP_E_HIP;
-    merge_stats(ctx->stats, ctx->slot[0].stats);
-    ctx->stats.total_ms = ctx->slot[0].stats.total_ms;
+    rc = run_batch(ctx, &ctx->slot[0], bp, &c, &r, /*explicit_guess=*/true);
+    {
+      std::lock_guard<std::mutex> lk(ctx->stats_mu);
+      reset_submit_stats(ctx->stats);
+      merge_stats(ctx->stats, ctx->slot[0].stats);
+      ctx->stats.total_ms = ctx->slot[0].stats.total_ms;
+    }
     if (rc == LGICP_OK) {
       std::memcpy(final_T, r.T_icp, sizeof(r.T_icp));
       if (converged) *converged = r.converged;

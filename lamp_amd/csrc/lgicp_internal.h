@@ -10,6 +10,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <string>
 #include <unordered_map>
@@ -213,9 +214,11 @@ struct SlotThreads {
   bool stop = false;
 
   void start(int n_helpers) {
+    // a restarted set must not take the last job of the previous one for a new job
+    const uint64_t born = generation;
     for (int k = 1; k <= n_helpers; ++k)
-      threads.emplace_back([this, k] {
-        uint64_t seen = 0;
+      threads.emplace_back([this, k, born] {
+        uint64_t seen = born;
         for (;;) {
           std::function<void(int)> fn;
           {
@@ -257,6 +260,9 @@ struct SlotThreads {
     cv_job.notify_all();
     for (std::thread& t : threads) t.join();
     threads.clear();
+    stop = false;  // start() may be called again
+    job = nullptr;
+    wanted = pending = 0;
   }
 };
 
@@ -275,7 +281,19 @@ struct lgicp_ctx {
   // parts of a submit in flight at once, one stream each (the GPU exposes 4 hardware queues
   // per process); reserved[7] overrides
   int n_slots = 4;
-  SlotThreads helpers;
+  // Submits that may run side by side, each on its own share of the slots (lgicp_set_submit_lanes):
+  // lane l owns slots [l * n_slots / n_lanes, (l + 1) * n_slots / n_lanes), the calling thread
+  // runs the first of them and helpers[l] the others.
+  static constexpr int MAX_LANES = 4;
+  int n_lanes = 1;
+  SlotThreads helpers[MAX_LANES];
+  std::mutex lane_mu;
+  std::condition_variable lane_cv;
+  bool lane_busy[MAX_LANES] = {false, false, false, false};
+  // keyframes and poses: submits read them (shared), registration and lgicp_align change them
+  std::shared_mutex data_mu;
+  std::mutex flush_mu;  // flush_registrations: one submit at a time
+  std::mutex stats_mu;
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
   Registry reg;                  // keyframe registration
   // bit matrices and matches of the pairs of a TEASERPP group, reused from submit to submit

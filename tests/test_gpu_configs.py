@@ -105,6 +105,64 @@ def test_batch_and_slot_independence():
             assert np.allclose(r["delta_R"] @ T[:3, 3] + r["delta_t"], 0, atol=1e-6)
 
 
+@pytest.mark.parametrize("lanes,threads", [(2, 2), (4, 4), (2, 5)])
+def test_submits_side_by_side_equal_submits_in_turn(lanes, threads):
+    """lgicp_set_submit_lanes: submits issued by several host threads at once (more threads than
+    lanes wait their turn) return what the same submits return one after the other, bit for bit;
+    a registration issued meanwhile waits for the submits in flight, and the keyframes it adds are
+    there for the next submit."""
+    import threading
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    works = [Workload("C2", pairs=48, points=4096, keyframes=8, shard=s, key_offset=100000 * s)
+             for s in range(threads)]
+    late = Workload("C2", pairs=8, points=4096, keyframes=4, shard=17, key_offset=9000000)
+
+    def to_dicts(res):
+        return [capi.result_to_dict(r) for r in res]
+
+    c = capi.Context(init_method=capi.INIT_IDENTITY)
+    try:
+        for w in works:
+            w.register(c)
+        serial = [to_dicts(c.submit(w.candidates())) for w in works]
+        assert c.set_submit_lanes(lanes) == lanes
+        got, errors = [None] * threads, []
+
+        def submitter(k):
+            try:
+                for _ in range(3):
+                    got[k] = to_dicts(c.submit(works[k].candidates()))
+            except Exception as e:   # noqa: BLE001 - reported by the main thread
+                errors.append(e)
+
+        def registrar():
+            try:
+                late.register(c)
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+
+        th = [threading.Thread(target=submitter, args=(k,)) for k in range(threads)]
+        th.append(threading.Thread(target=registrar))
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        for a_list, b_list in zip(serial, got):
+            for a, b in zip(a_list, b_list):
+                assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
+                assert np.array_equal(a["T_icp"], b["T_icp"]) and a["fitness"] == b["fitness"]
+                assert np.array_equal(a["information"], b["information"])
+        res = to_dicts(c.submit(late.candidates()))
+        assert sum(r["status"] == 0 for r in res) >= 6
+        assert c.set_submit_lanes(1) == 1
+        again = to_dicts(c.submit(works[0].candidates()))
+        assert all(np.array_equal(a["T_icp"], b["T_icp"]) for a, b in zip(serial[0], again))
+    finally:
+        c.close()
+
+
 def test_small_workspace_cuts_the_submit_into_sub_batches():
     """workspace_bytes bounds the per-batch scratch (configuration C5 does not fit one batch):
     the results do not depend on where the cuts fall."""

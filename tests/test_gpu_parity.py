@@ -160,6 +160,28 @@ def test_align_matches_oracle(ctx, n, seed, rd, tr):
     assert abs(fit - r["fitness"]) <= 1e-5 * abs(fit)
 
 
+def test_align_special_and_unnormalised_normals_match_oracle(ctx):
+    """The reduction rebuilds covariances from the stored normals in closed form and takes the
+    stored matrix wherever the reference's construction (gicp_utils.h:28-48) leaves that form:
+    zero normals, a z component clamped before or after normalisation.  A cloud that mixes all of
+    those with normals of arbitrary length must still follow the CPU restatement."""
+    src, sn, tgt, tn, T = F.make_pair(6000, 11, rot_deg=2.5, trans=0.2)
+    rng = np.random.default_rng(3)
+    for n in (sn, tn):
+        k = rng.permutation(len(n))
+        n[k[:300]] = 0.0                                   # nothing to normalise
+        n[k[300:900], 2] = 0.0                             # z clamped before normalisation
+        n[k[900:1200], 2] = np.float32(5e-8)               # ... and after
+        n[k[1200:1500], 2] = np.float32(3e-7)              # just outside the clamp: closed form
+        n[k[1500:3000]] *= rng.uniform(0.3, 3.0, (1500, 1)).astype(np.float32)  # any length
+    r = ctx.align(src, sn, tgt, tn, np.eye(4))
+    gn = O.gicp_align(O.base_gicp_params(solver=O.SOLVER_GN, use_kdtree=1), src, sn, tgt, tn, np.eye(4))
+    assert r["converged"] and gn["converged"]
+    ang, tr_err = _rot_err(gn["T"], r["T"])
+    assert ang < 1e-5 and tr_err < 1e-5, (ang, tr_err)
+    assert r["iterations"] == gn["iterations"]
+
+
 def test_align_uses_the_callers_guess_whatever_the_init_method():
     """lgicp_align on a context with the reference's default initialisation (FEATURES, what
     lgicp_default_config sets) and with TEASERPP: the explicit guess goes to GICP as it is, no
