@@ -340,28 +340,48 @@ def main():
         return out
 
     def collect_overlapped(n_steps, first, depth):
-        """`depth` steps in flight, each submitted by a pool thread; results are taken (and, with
-        several ranks, gathered) in step order by this thread.  Stage times are what lgicp_get_stats
+        """`depth` steps in flight, each lane of steps submitted by its own thread; results are
+        taken (and, with several ranks, gathered) in step order by this thread.  Stage times are what lgicp_get_stats
         reports as "last submit" when a step returns: with submits side by side that is now and
         then the neighbour's, so the sums are indicative; the launch and distance counters are
         exact differences over the region."""
-        from collections import deque
-        from concurrent.futures import ThreadPoolExecutor
+        import threading
         acc = dict(nn_ms=0.0, nn_launches=0.0, nn_evals=0.0, nn_exec=0.0, red_ms=0.0,
                    red_launches=0.0, red_points=0.0, red_inliers=0.0, cycle_exits=0.0,
                    clique_ms=0.0, clique_bytes=0.0, clique_launches=0.0,
                    hindex_ms=0.0, hindex_bytes=0.0, hindex_launches=0.0)
         stage = dict(nn=0.0, reduce=0.0, solve=0.0, cov=0.0, post=0.0, total=0.0)
-        res = []
         s_begin = ctx.stats()
+        done, cv, failed = {}, threading.Condition(), []
 
-        def one(i):
-            out = ctx.submit_packed(packed_sets[i % depth][i % n_batches])
-            return i, out, ctx.stats()
+        def lane_loop(k):
+            # steps first + k, first + k + depth, ...: a lane never waits for the others
+            try:
+                for i in range(first + k, first + n_steps, depth):
+                    out = ctx.submit_packed(packed_sets[k][i % n_batches])
+                    rec = pack_results(out, len(cand_lists[i % n_batches])) if dist is not None else None
+                    with cv:
+                        done[i] = (out, rec, ctx.stats())
+                        cv.notify_all()
+            except Exception as e:   # noqa: BLE001 - raised again by the main thread
+                with cv:
+                    failed.append(e)
+                    cv.notify_all()
 
-        def finish(fut):
-            i, out, s1 = fut.result()
-            gather(i, out)
+        threads = [threading.Thread(target=lane_loop, args=(k,)) for k in range(depth)]
+        for t in threads:
+            t.start()
+        res = []
+        for i in range(first, first + n_steps):   # results in step order (the gather is a collective)
+            with cv:
+                cv.wait_for(lambda: i in done or failed)
+                if failed:
+                    break
+                out, rec, s1 = done.pop(i)
+            if rec is not None:
+                import torch
+                gatherer.gather(rec)
+                torch.cuda.synchronize()
             res.append(out)
             acc["nn_ms"] += s1.nn_ms
             acc["nn_exec"] += s1.nn_executed_evals
@@ -372,15 +392,10 @@ def main():
             acc["cycle_exits"] += s1.cycle_exits
             for k in stage:
                 stage[k] += getattr(s1, k + "_ms")
-
-        with ThreadPoolExecutor(depth) as pool:
-            pending = deque()
-            for i in range(first, first + n_steps):
-                if len(pending) == depth:
-                    finish(pending.popleft())
-                pending.append(pool.submit(one, i))
-            while pending:
-                finish(pending.popleft())
+        for t in threads:
+            t.join()
+        if failed:
+            raise failed[0]
         s_end = ctx.stats()
         acc["nn_launches"] = s_end.nn_launches - s_begin.nn_launches
         acc["nn_evals"] = s_end.nn_distance_evals - s_begin.nn_distance_evals
