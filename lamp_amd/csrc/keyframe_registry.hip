@@ -321,8 +321,8 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
     const size_t n = (size_t)std::max(L.n, 1), t = (size_t)std::max(L.n_tiles, 1);
     L.order = bytes, bytes += align256(sizeof(int) * n);
     L.sxyz = bytes, bytes += align256(sizeof(float4) * t * SI_TILE);
-    L.tmin = bytes, bytes += align256(sizeof(float4) * t);
-    L.tmax = bytes, bytes += align256(sizeof(float4) * t);
+    L.tmin = bytes, bytes += align256(sizeof(float4) * (t + (t + 63) / 64));  // tiles, blocks of 64 tiles
+    L.tmax = bytes, bytes += align256(sizeof(float4) * (t + (t + 63) / 64));
     L.qorder = bytes, bytes += align256(sizeof(int) * (size_t)std::max(L.n_q, 64));
     L.cov = L.rec = L.cnrm = L.nrm_x = 0;
     if (derive) {

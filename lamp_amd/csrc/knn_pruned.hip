@@ -192,15 +192,42 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
   float hi = __builtin_fminf(worst < __builtin_inff() ? __builtin_fmaxf(r0sq, worst * WIDEN) : r0sq, capsel);
   const int n_steps = (n_tiles + 63) / 64;
 
+  const float4* __restrict__ const gmin = tmin + n_tiles;  // boxes of the blocks of 64 tiles
+  const float4* __restrict__ const gmax = tmax + n_tiles;
   for (;;) {
     wround = worst;
-    // boxes of the next 64 tiles are fetched while the current 64 are being worked on
-    float4 nb0 = make_float4(0.f, 0.f, 0.f, 0.f), nb1 = nb0;
-    if (lane < n_tiles) nb0 = tmin[lane], nb1 = tmax[lane];
-    for (int step = 0; step < n_steps; ++step) {
+    const float sel = __builtin_fminf(hi, wround * WIDEN);  // no tile beyond this gap is selected
+    // The blocks of 64 consecutive tiles first, 64 of them at once: a block whose box lies beyond
+    // `sel` holds no tile of this round (its gap bounds the gap of every tile inside from below),
+    // and in k-d order most blocks of a cloud are far from the patch.
+    for (int sb0 = 0; sb0 < n_steps; sb0 += 64) {
+      bool take = false;
+      if (sb0 + lane < n_steps) {
+        const float4 g0 = gmin[sb0 + lane], g1 = gmax[sb0 + lane];
+        const float gx = __builtin_fmaxf(0.f, __builtin_fmaxf(g0.x - qx1, qx0 - g1.x));
+        const float gy = __builtin_fmaxf(0.f, __builtin_fmaxf(g0.y - qy1, qy0 - g1.y));
+        const float gz = __builtin_fmaxf(0.f, __builtin_fmaxf(g0.z - qz1, qz0 - g1.z));
+        take = (gx * gx + gy * gy) + gz * gz <= sel;  // false for an empty block (gap +inf)
+      }
+      unsigned long long smask = __ballot(take);
+      // tile boxes of the next block to visit are fetched while the current one is worked on
+      int step = -1;
+      float4 nb0 = make_float4(0.f, 0.f, 0.f, 0.f), nb1 = nb0;
+      if (smask) {
+        step = sb0 + __builtin_ctzll(smask);
+        smask &= smask - 1;
+        if (step * 64 + lane < n_tiles) nb0 = tmin[step * 64 + lane], nb1 = tmax[step * 64 + lane];
+      }
+      while (step >= 0) {
       const float4 b0 = nb0, b1 = nb1;
       const int t = step * 64 + lane;
-      if (t + 64 < n_tiles) nb0 = tmin[t + 64], nb1 = tmax[t + 64];
+      const int cur = step;
+      step = -1;
+      if (smask) {
+        step = sb0 + __builtin_ctzll(smask);
+        smask &= smask - 1;
+        if (step * 64 + lane < n_tiles) nb0 = tmin[step * 64 + lane], nb1 = tmax[step * 64 + lane];
+      }
       // patch-to-tile gap: which of these 64 tiles belong to this round at all
       const float gx = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.x - qx1, qx0 - b1.x));
       const float gy = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.y - qy1, qy0 - b1.y));
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
           ruled = __builtin_fminf(ruled, gl);
           continue;
         }
-        const int tile = step * 64 + b;
+        const int tile = cur * 64 + b;
         cfloat* const tx = tiles + (size_t)tile * (4 * SI_TILE);
         cfloat* const ty = tx + SI_TILE;
         cfloat* const tz = tx + 2 * SI_TILE;
@@ -254,6 +281,7 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
         ++visited;
 #endif
       }
+    }
     }
     worst = wave_max_nonneg(need ? bestd : 0.f);
     if (hi >= capsel || worst * WIDEN <= hi) break;

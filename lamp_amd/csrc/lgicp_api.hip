@@ -505,7 +505,7 @@ int plan_cloud(lgicp_ctx* ctx, BatchPlan& bp, uint64_t key, bool accumulate) {
   if (acc) {
     bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 32 + 1024;  // xyz + normals (+ estimated)
     // spatial index: tile-ordered points, boxes, visiting order
-    bp.bytes += (size_t)cp.n * 22 + (cp.segs.size() + 1) * (SI_TILE * 16 + 64) + 2048;
+    bp.bytes += (size_t)cp.n * 23 + (cp.segs.size() + 1) * (SI_TILE * 16 + 64) + 4096;
   }
   const int idx = (int)bp.clouds.size();
   bp.clouds.push_back(std::move(cp));
@@ -588,8 +588,8 @@ void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t
         cd.n_tiles = tiles;
         cd.n_q = round_up(cp.n, 64);
         float4* sx = ar.take<float4>((size_t)tiles * SI_TILE);
-        float4* t0 = ar.take<float4>((size_t)tiles);
-        float4* t1 = ar.take<float4>((size_t)tiles);
+        float4* t0 = ar.take<float4>((size_t)tiles + (tiles + 63) / 64);  // tiles, blocks of 64 tiles
+        float4* t1 = ar.take<float4>((size_t)tiles + (tiles + 63) / 64);
         int* qo = ar.take<int>((size_t)cd.n_q);
         cd.sxyz = sx, cd.tmin = t0, cd.tmax = t1, cd.qorder = qo;
         IndexSegDev g;

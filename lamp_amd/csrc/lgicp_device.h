@@ -54,8 +54,8 @@ struct CloudDev {
   const float4* sxyz;  // n_tiles tiles of SI_TILE points in k-d partition order, each tile stored as
                        // x[SI_TILE] y[SI_TILE] z[SI_TILE] original-index[SI_TILE]; unused
                        // slots hold +inf coordinates and index -1
-  const float4* tmin;  // n_tiles box corners
-  const float4* tmax;
+  const float4* tmin;  // n_tiles box corners, then the boxes of the ceil(n_tiles / 64) blocks of 64
+  const float4* tmax;  // consecutive tiles (spatial_index.hip)
   const int* qorder;   // n_q original indices in visiting order, -1 in the padding
   int n_tiles;
   int n_q;             // n rounded up to a multiple of 64
@@ -185,7 +185,7 @@ struct IndexSegDev {
   const float4* xyz;   // the cloud's points in original order
   const int* order;    // visiting order of this segment's own points
   float4* sxyz;
-  float4* tmin;
+  float4* tmin;        // room for the cloud's tiles plus one entry per block of 64 tiles
   float4* tmax;
   int* qorder;
   int point_off;       // first original index of the segment inside the cloud
