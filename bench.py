@@ -233,7 +233,7 @@ def main():
                     help="parts of a submit in flight at once (0 = the library's default)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="submits in flight at once, each from its own host thread "
-                         "(lgicp_set_submit_lanes; 0 = 4 for the GICP-only configurations, 1 for C4)")
+                         "(lgicp_set_submit_lanes; 0 = 6 for the GICP-only configurations, 1 for C4)")
     ap.add_argument("--exhaustive", action="store_true",
                     help="use the exhaustive 1-NN kernel instead of the pruned one")
     args = ap.parse_args()
@@ -288,7 +288,7 @@ def main():
     # Steps overlap: the last outer iterations of a batch (a handful of pairs, latency-bound) run
     # beside the full-size launches of the next ones.  Feature-based initialisations take the whole
     # context per submit, so C4 stays at one.
-    in_flight = args.in_flight or (1 if args.config == "C4" else 4)
+    in_flight = args.in_flight or (1 if args.config == "C4" or args.slots == 1 else 6)
     if in_flight > 1:
         in_flight = ctx.set_submit_lanes(in_flight)
 

@@ -256,6 +256,7 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
     ctx->n_slots = cfg->reserved[7];
   std::vector<hipStream_t> streams = concurrent_streams(ctx->n_slots, /*probe=*/cfg->reserved[7] < 1);
   ctx->n_slots = std::max<int>(1, std::min<int>(ctx->n_slots, (int)streams.size()));
+  ctx->n_wide = ctx->n_slots;
   bool slots_ok = !streams.empty();
   for (int k = 0; k < ctx->n_slots && slots_ok; ++k) slots_ok = ctx->slot[k].create(streams[k]);
   if (!slots_ok) {
@@ -406,7 +407,21 @@ int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes) {
   if (lanes < 1) return fail(ctx, LGICP_E_INVALID, "lanes must be >= 1");
   std::unique_lock<std::shared_mutex> data(ctx->data_mu);
   AllLanes all(ctx);
-  lanes = std::min(lanes, std::min<int>(lgicp_ctx::MAX_LANES, ctx->n_slots));
+  lanes = std::min<int>(lanes, lgicp_ctx::MAX_LANES);
+  // More lanes than the context has slots: further slots on streams of their own.  They share the
+  // process's hardware queues with the first ones, which is what is wanted here (a lane's work is
+  // a chain of dependent launches with host round trips in between; a queue serves another lane
+  // meanwhile); one submit is never spread over them.
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  while (ctx->n_slots < lanes) {
+    hipStream_t s = nullptr;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (!ctx->slot[ctx->n_slots].create(s)) {
+      ctx->slot[ctx->n_slots].destroy();
+      return fail(ctx, LGICP_E_HIP, "pinned allocation failed");
+    }
+    ++ctx->n_slots;
+  }
   for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->helpers[l].shutdown();
   ctx->n_lanes = lanes;
   for (int l = 0; l < lanes; ++l) ctx->helpers[l].start(ctx->n_slots / lanes - 1);
@@ -1483,7 +1498,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   std::unique_ptr<AllLanes> hold_all(whole_context ? new AllLanes(ctx) : nullptr);
   std::unique_ptr<OneLane> hold_one(whole_context ? nullptr : new OneLane(ctx));
   const int lane = hold_one ? hold_one->lane : 0;
-  const int lane_slots = hold_one ? ctx->n_slots / ctx->n_lanes : ctx->n_slots;
+  const int lane_slots = hold_one ? ctx->n_slots / ctx->n_lanes : ctx->n_wide;
   const int first_slot = lane * lane_slots;
   // with several lanes configured lane 0's helpers serve fewer slots than a whole-context
   // submit could use: it runs on the slots they cover
@@ -1527,7 +1542,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
 
   std::atomic<int> rc_all{LGICP_OK};
   std::mutex stats_mu;
-  double slot_total_ms[lgicp_ctx::MAX_SLOTS] = {0, 0, 0, 0};
+  double slot_total_ms[lgicp_ctx::MAX_SLOTS] = {};
   std::vector<BatchPlan> plans;
   std::atomic<bool> plans_ready{false};
   auto worker = [&](int si) {

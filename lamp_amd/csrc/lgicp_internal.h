@@ -276,20 +276,21 @@ struct lgicp_ctx {
   int nn_variant = 4;
   bool nn_exhaustive = false;  // reserved[2] = 1: the dense 1-NN kernel instead of the pruned one
   float nn_r0sq = 1.0f / 64.0f;  // squared radius of the pruned search's first round
-  static constexpr int MAX_SLOTS = 4;
+  static constexpr int MAX_SLOTS = 8;
   BatchSlot slot[MAX_SLOTS];
   // parts of a submit in flight at once, one stream each (the GPU exposes 4 hardware queues
   // per process); reserved[7] overrides
   int n_slots = 4;
+  int n_wide = 4;  // the first n_wide slots' streams were found to overlap: what one submit spreads over
   // Submits that may run side by side, each on its own share of the slots (lgicp_set_submit_lanes):
   // lane l owns slots [l * n_slots / n_lanes, (l + 1) * n_slots / n_lanes), the calling thread
   // runs the first of them and helpers[l] the others.
-  static constexpr int MAX_LANES = 4;
+  static constexpr int MAX_LANES = 8;
   int n_lanes = 1;
   SlotThreads helpers[MAX_LANES];
   std::mutex lane_mu;
   std::condition_variable lane_cv;
-  bool lane_busy[MAX_LANES] = {false, false, false, false};
+  bool lane_busy[MAX_LANES] = {};
   // keyframes and poses: submits read them (shared), registration and lgicp_align change them
   std::shared_mutex data_mu;
   std::mutex flush_mu;  // flush_registrations: one submit at a time

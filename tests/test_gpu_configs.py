@@ -105,7 +105,7 @@ def test_batch_and_slot_independence():
             assert np.allclose(r["delta_R"] @ T[:3, 3] + r["delta_t"], 0, atol=1e-6)
 
 
-@pytest.mark.parametrize("lanes,threads", [(2, 2), (4, 4), (2, 5)])
+@pytest.mark.parametrize("lanes,threads", [(2, 2), (4, 4), (2, 5), (6, 6)])
 def test_submits_side_by_side_equal_submits_in_turn(lanes, threads):
     """lgicp_set_submit_lanes: submits issued by several host threads at once (more threads than
     lanes wait their turn) return what the same submits return one after the other, bit for bit;
