@@ -20,7 +20,9 @@
 // the patch lies in (r_{k-1}^2, r_k^2]; the sweep ends when every lane's best is <= r_k^2
 // (nothing further out can matter) or, for the bounded search of the GICP loop, when r_k^2
 // reaches the correspondence threshold (the loop ignores matches at or beyond it,
-// gicp.hpp:476).  Inside a round the 64 lanes test 64 tile boxes at once; for each survivor the
+// gicp.hpp:476).  A round first tests the boxes of the blocks of 64 consecutive tiles, 64 blocks at
+// once, and goes into the blocks that can hold a tile of the round.  Inside a block the 64 lanes
+// test its 64 tile boxes at once; for each survivor the
 // box is broadcast and every lane tests its own query against it, and the tile is walked only
 // if some lane can still improve or tie.  Tile coordinates arrive through scalar loads, two
 // targets per packed instruction.  As in the exhaustive kernel a lane tracks only the minimum of each group
@@ -219,69 +221,69 @@ __global__ __launch_bounds__(NNP_THREADS) void nn_pruned_kernel(
         if (step * 64 + lane < n_tiles) nb0 = tmin[step * 64 + lane], nb1 = tmax[step * 64 + lane];
       }
       while (step >= 0) {
-      const float4 b0 = nb0, b1 = nb1;
-      const int t = step * 64 + lane;
-      const int cur = step;
-      step = -1;
-      if (smask) {
-        step = sb0 + __builtin_ctzll(smask);
-        smask &= smask - 1;
-        if (step * 64 + lane < n_tiles) nb0 = tmin[step * 64 + lane], nb1 = tmax[step * 64 + lane];
-      }
-      // patch-to-tile gap: which of these 64 tiles belong to this round at all
-      const float gx = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.x - qx1, qx0 - b1.x));
-      const float gy = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.y - qy1, qy0 - b1.y));
-      const float gz = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.z - qz1, qz0 - b1.z));
-      const float lb = (gx * gx + gy * gy) + gz * gz;
-      unsigned long long mask = __ballot(t < n_tiles && lb > lo && lb <= hi && lb <= wround * WIDEN);
-      while (mask) {
-        const int b = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        // query-to-tile gap per lane: the tile is skipped unless it can improve or tie some
-        // lane's current best (and, in the bounded search, lies inside the cap for it)
-        const float x0 = rdlane(b0.x, b), y0 = rdlane(b0.y, b), z0 = rdlane(b0.z, b);
-        const float x1 = rdlane(b1.x, b), y1 = rdlane(b1.y, b), z1 = rdlane(b1.z, b);
-        const float hx = __builtin_fmaxf(0.f, __builtin_fmaxf(x0 - x, x - x1));
-        const float hy = __builtin_fmaxf(0.f, __builtin_fmaxf(y0 - y, y - y1));
-        const float hz = __builtin_fmaxf(0.f, __builtin_fmaxf(z0 - z, z - z1));
-        const float gl = (hx * hx + hy * hy) + hz * hz;
+        const float4 b0 = nb0, b1 = nb1;
+        const int t = step * 64 + lane;
+        const int cur = step;
+        step = -1;
+        if (smask) {
+          step = sb0 + __builtin_ctzll(smask);
+          smask &= smask - 1;
+          if (step * 64 + lane < n_tiles) nb0 = tmin[step * 64 + lane], nb1 = tmax[step * 64 + lane];
+        }
+        // patch-to-tile gap: which of these 64 tiles belong to this round at all
+        const float gx = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.x - qx1, qx0 - b1.x));
+        const float gy = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.y - qy1, qy0 - b1.y));
+        const float gz = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.z - qz1, qz0 - b1.z));
+        const float lb = (gx * gx + gy * gy) + gz * gz;
+        unsigned long long mask = __ballot(t < n_tiles && lb > lo && lb <= hi && lb <= wround * WIDEN);
+        while (mask) {
+          const int b = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          // query-to-tile gap per lane: the tile is skipped unless it can improve or tie some
+          // lane's current best (and, in the bounded search, lies inside the cap for it)
+          const float x0 = rdlane(b0.x, b), y0 = rdlane(b0.y, b), z0 = rdlane(b0.z, b);
+          const float x1 = rdlane(b1.x, b), y1 = rdlane(b1.y, b), z1 = rdlane(b1.z, b);
+          const float hx = __builtin_fmaxf(0.f, __builtin_fmaxf(x0 - x, x - x1));
+          const float hy = __builtin_fmaxf(0.f, __builtin_fmaxf(y0 - y, y - y1));
+          const float hz = __builtin_fmaxf(0.f, __builtin_fmaxf(z0 - z, z - z1));
+          const float gl = (hx * hx + hy * hy) + hz * hz;
 #ifdef NNP_COUNT_CONSIDERED  // diagnostics build: the counter reports tiles tested, not tiles walked
-        ++visited;
+          ++visited;
 #endif
-        if (__ballot(need && gl <= bestd && gl <= cap) == 0) {
-          ruled = __builtin_fminf(ruled, gl);
-          continue;
-        }
-        const int tile = cur * 64 + b;
-        cfloat* const tx = tiles + (size_t)tile * (4 * SI_TILE);
-        cfloat* const ty = tx + SI_TILE;
-        cfloat* const tz = tx + 2 * SI_TILE;
-#pragma unroll
-        for (int g = 0; g < SI_TILE / GROUP; ++g) {
-          float m = __builtin_inff();
-#pragma unroll
-          for (int j = 0; j < GROUP; j += 2) {
-            const int kk = g * GROUP + j;
-            const v2f px = {tx[kk], tx[kk + 1]}, py = {ty[kk], ty[kk + 1]}, pz = {tz[kk], tz[kk + 1]};
-            const v2f dx = x2 - px, dy = y2 - py, dz = z2 - pz;
-            const v2f d = (dx * dx + dy * dy) + dz * dz;
-            m = __builtin_fminf(__builtin_fminf(m, d.x), d.y);
+          if (__ballot(need && gl <= bestd && gl <= cap) == 0) {
+            ruled = __builtin_fminf(ruled, gl);
+            continue;
           }
-          // +inf and NaN distances (padding, overflow) never count
-          // a seeded bound counts as reached by the first group that equals it
-          const bool lower = m < bestd || (m == bestd && bgrp < 0);
-          // the loser of the comparison is a target other than the final match (a seeded bound
-          // that no group has reached yet is the match itself or shows up again later)
-          second = __builtin_fminf(second, lower ? (bgrp >= 0 ? bestd : __builtin_inff()) : m);
-          tie = lower ? false : (tie || m == bestd);
-          bestd = lower ? m : bestd;
-          bgrp = lower ? tile * (SI_TILE / GROUP) + g : bgrp;
-        }
+          const int tile = cur * 64 + b;
+          cfloat* const tx = tiles + (size_t)tile * (4 * SI_TILE);
+          cfloat* const ty = tx + SI_TILE;
+          cfloat* const tz = tx + 2 * SI_TILE;
+#pragma unroll
+          for (int g = 0; g < SI_TILE / GROUP; ++g) {
+            float m = __builtin_inff();
+#pragma unroll
+            for (int j = 0; j < GROUP; j += 2) {
+              const int kk = g * GROUP + j;
+              const v2f px = {tx[kk], tx[kk + 1]}, py = {ty[kk], ty[kk + 1]}, pz = {tz[kk], tz[kk + 1]};
+              const v2f dx = x2 - px, dy = y2 - py, dz = z2 - pz;
+              const v2f d = (dx * dx + dy * dy) + dz * dz;
+              m = __builtin_fminf(__builtin_fminf(m, d.x), d.y);
+            }
+            // +inf and NaN distances (padding, overflow) never count
+            // a seeded bound counts as reached by the first group that equals it
+            const bool lower = m < bestd || (m == bestd && bgrp < 0);
+            // the loser of the comparison is a target other than the final match (a seeded bound
+            // that no group has reached yet is the match itself or shows up again later)
+            second = __builtin_fminf(second, lower ? (bgrp >= 0 ? bestd : __builtin_inff()) : m);
+            tie = lower ? false : (tie || m == bestd);
+            bestd = lower ? m : bestd;
+            bgrp = lower ? tile * (SI_TILE / GROUP) + g : bgrp;
+          }
 #ifndef NNP_COUNT_CONSIDERED
-        ++visited;
+          ++visited;
 #endif
+        }
       }
-    }
     }
     worst = wave_max_nonneg(need ? bestd : 0.f);
     if (hi >= capsel || worst * WIDEN <= hi) break;
