@@ -230,8 +230,11 @@ int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n, lgicp_re
  * callers wait their turn); registration (lgicp_add_keyframe(s), lgicp_add_pose,
  * lgicp_wait_registered) and lgicp_align wait for the submits in flight and hold new ones off
  * while they run; submits with a feature-based initialisation (FEATURES, TEASERPP) take the whole
- * context whatever the setting.  lgicp_get_stats' "last submit" fields describe whichever submit
- * ended last.  Returns the number of lanes now in effect, or a negative LGICP_E_* code. */
+ * context whatever the setting.  The single-operation entry points below (lgicp_nn_search,
+ * lgicp_fpfh, ...) use the context's first stream and are not to be called while submits are in
+ * flight.  Every lane holds its own batch buffers (sized by its largest batch so far, at most
+ * workspace_bytes of device memory each).  lgicp_get_stats' "last submit" fields describe
+ * whichever submit ended last.  Returns the number of lanes now in effect, or a negative LGICP_E_* code. */
 int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes);
 
 int lgicp_get_stats(const lgicp_ctx* ctx, lgicp_stats* out);

@@ -1076,7 +1076,9 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     // on the batch it travels in): short per-lane chains keep the stragglers' iterations short
     h_ints[p] = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + 1023) / 1024));
     const int tiles = bp.clouds[bp.pairs[p].tgt_cloud].n_pad / NN_TILE;
-    max_nn_blocks += (size_t)((pd.n_src + QB - 1) / QB) * (size_t)std::min(64, tiles);
+    // the exhaustive kernel may split a query tile's target sweep over up to 64 blocks; the pruned
+    // kernel has one block per 64 queries
+    max_nn_blocks += (size_t)((pd.n_src + QB - 1) / QB) * (size_t)(ctx->nn_exhaustive ? std::min(64, tiles) : 1);
     evals_per_pass += (double)pd.n_src * (double)pd.n_tgt;
   }
   build_maps(all_pairs);
