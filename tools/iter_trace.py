@@ -7,6 +7,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lamp_amd import capi  # noqa: E402
+if os.environ.get("LGICP_LIB"):   # another build of the library (A/B comparisons)
+    capi.LIB_PATH = os.path.abspath(os.environ["LGICP_LIB"])
 from lamp_amd.workload import Workload  # noqa: E402
 
 cfg_name = sys.argv[1] if len(sys.argv) > 1 else "C2"
