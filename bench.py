@@ -381,7 +381,9 @@ def main():
             if rec is not None:
                 import torch
                 gatherer.gather(rec)
-                torch.cuda.synchronize()
+                # the collective's own stream only: a device-wide wait would also sit out whatever
+                # the other lanes have in flight (the closing barrier() waits for the device)
+                torch.cuda.current_stream().synchronize()
             res.append(out)
             acc["nn_ms"] += s1.nn_ms
             acc["nn_exec"] += s1.nn_executed_evals
