@@ -19,8 +19,10 @@
 // The shape of the k-d partition is a function of the number of finite points alone, so no range
 // tables are needed: every point finds its range at a level by descending from the root.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -336,7 +338,10 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
   if (R.ev_stage) HIP_TRY(ctx, hipEventSynchronize(R.ev_stage));
   else HIP_TRY(ctx, hipEventCreateWithFlags(&R.ev_stage, hipEventDisableTiming));
   HIP_TRY(ctx, pinned_reserve(&R.h_stage, &R.stage_cap, up_bytes));
-  for (size_t k = 0; k < count; ++k) {
+  // Staging is a plain per-point copy into float4 layout (plus the count of finite points): the
+  // host's share of a registration, and for a batch of a million points most of its wall time when
+  // one thread does it.  Keyframes are dealt out to a few threads.
+  auto stage_one = [&](size_t k) {
     Lay& L = lay[k];
     float4* hx = reinterpret_cast<float4*>(R.h_stage + L.xyz);
     float4* hn = reinterpret_cast<float4*>(R.h_stage + L.nrm);
@@ -357,8 +362,25 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
     L.nf = nf;
     // lamp_utils::ExtractNormals looks at the first stored normal only (PointCloudUtils.cc:17-35)
     L.missing = derive && L.n > 0 && hn[0].x == 0.f && hn[0].y == 0.f && hn[0].z == 0.f;
-    if (L.missing) L.nrm_x = bytes, bytes += align256(sizeof(float4) * (size_t)L.n);
+  };
+  {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t n_thr = std::min<size_t>({(size_t)8, (size_t)hw, count, total_pts / 65536 + 1});
+    if (n_thr <= 1) {
+      for (size_t k = 0; k < count; ++k) stage_one(k);
+    } else {
+      std::atomic<size_t> next{0};
+      auto work = [&] {
+        for (size_t k = next.fetch_add(1); k < count; k = next.fetch_add(1)) stage_one(k);
+      };
+      std::vector<std::thread> pool;
+      for (size_t t = 1; t < n_thr; ++t) pool.emplace_back(work);
+      work();
+      for (std::thread& t : pool) t.join();
+    }
   }
+  for (size_t k = 0; k < count; ++k)
+    if (lay[k].missing) lay[k].nrm_x = bytes, bytes += align256(sizeof(float4) * (size_t)lay[k].n);
 
   auto block = std::make_shared<DevBlock>();
   HIP_TRY(ctx, hipMalloc((void**)&block->p, std::max<size_t>(bytes, 256)));
