@@ -3,6 +3,8 @@
 import os, sys, time, threading
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lamp_amd import capi
+if os.environ.get("LGICP_LIB"):   # another build of the library (A/B comparisons)
+    capi.LIB_PATH = os.path.abspath(os.environ["LGICP_LIB"])
 from lamp_amd.workload import Workload
 
 slots, lanes = int(sys.argv[1]), int(sys.argv[2])
