@@ -453,18 +453,18 @@ int lgicp_add_pose(lgicp_ctx* ctx, uint64_t key, const double q[4], const double
 
 int lgicp_has_keyframe(const lgicp_ctx* ctx, uint64_t key) {
   if (!ctx) return 0;
-  std::shared_lock<std::shared_mutex> data(const_cast<lgicp_ctx*>(ctx)->data_mu);
+  std::shared_lock<std::shared_mutex> data(ctx->data_mu);
   return ctx->scans.count(key) ? 1 : 0;
 }
 int lgicp_has_pose(const lgicp_ctx* ctx, uint64_t key) {
   if (!ctx) return 0;
-  std::shared_lock<std::shared_mutex> data(const_cast<lgicp_ctx*>(ctx)->data_mu);
+  std::shared_lock<std::shared_mutex> data(ctx->data_mu);
   return ctx->poses.count(key) ? 1 : 0;
 }
 
 int lgicp_get_stats(const lgicp_ctx* ctx, lgicp_stats* out) {
   if (!ctx || !out) return LGICP_E_INVALID;
-  std::lock_guard<std::mutex> lk(const_cast<lgicp_ctx*>(ctx)->stats_mu);
+  std::lock_guard<std::mutex> lk(ctx->stats_mu);
   *out = ctx->stats;
   return LGICP_OK;
 }

@@ -292,9 +292,9 @@ struct lgicp_ctx {
   std::condition_variable lane_cv;
   bool lane_busy[MAX_LANES] = {};
   // keyframes and poses: submits read them (shared), registration and lgicp_align change them
-  std::shared_mutex data_mu;
+  mutable std::shared_mutex data_mu;
   std::mutex flush_mu;  // flush_registrations: one submit at a time
-  std::mutex stats_mu;
+  mutable std::mutex stats_mu;
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
   Registry reg;                  // keyframe registration
   // bit matrices and matches of the pairs of a TEASERPP group, reused from submit to submit
