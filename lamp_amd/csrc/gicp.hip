@@ -10,7 +10,7 @@
 // The residual res = Theta*(p,1) - q is linear in the 12 entries of Theta = [R|t], so the
 // objective (1/m) sum res^T M res of one outer iteration is a quadratic form in
 // delta = vec(Theta - Theta0).  One pass over the correspondences reduces it to 74 doubles
-// per pair (f64 matrix instructions within a wave, LDS across the 4 waves, one slab per chunk);
+// per pair (f64 matrix instructions within a wave, one wave and one slab per chunk);
 // the Gauss-Newton iterations on the 6 Euler parameters then cost O(1) each and run in the
 // solve kernel, which also applies the reference's convergence test and produces the next
 // float transformation with the reference's applyState arithmetic (gicp.hpp:619-634).
@@ -84,7 +84,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // COMPACT: every cloud of the launch carries flagged normals and 32-byte records (covariances
 // from normals); otherwise stored covariances and 64-byte records (covariances from k-NN)
 template <bool COMPACT>
-__global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
+__global__ __launch_bounds__(RED_THREADS, 3) void gicp_reduce_kernel(
     const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
     const PairState* __restrict__ st, const int4* __restrict__ bmap, double corr_dist2,
     double* __restrict__ partials) {
@@ -144,77 +144,16 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
   const int per = (n + bm.z - 1) / bm.z;
   const int i0 = bm.y * per;
   const int i1 = min(n, i0 + per);
-  // The matches of several rounds are fetched ahead: a round then waits for one memory latency
-  // (its gathers) instead of two in a row (match, then gathers).
-  constexpr int AHEAD = 4;
-  for (int gbase = i0 + wave * 64; gbase < i1; gbase += AHEAD * RED_THREADS) {  // wave-uniform
-   nnkey_t kahead[AHEAD];
-#pragma unroll
-   for (int r = 0; r < AHEAD; ++r) {
-     const int i = gbase + r * RED_THREADS + lane;
-     kahead[r] = i < i1 ? keys[i] : NNKEY_NONE;
-   }
-#pragma unroll
-   for (int r = 0; r < AHEAD; ++r) {
-    const int base = gbase + r * RED_THREADS;
-    if (base >= i1) break;
-    const int i = base + lane;
-    // a lane without a correspondence contributes b = 0; its a keeps the (finite) values of an
-    // earlier round, whose products with zero add nothing
+  // One round of 64 points, given S = R C1 R^T + C2 of every lane that holds a correspondence: M,
+  // residual, the two operand vectors, staging and the matrix instructions.  A lane without a
+  // correspondence contributes b = 0; its a keeps the (finite) values of an earlier round, whose
+  // products with zero add nothing.
+  auto accumulate = [&](bool valid, const float4 pf, const float4 qf, double s00, double s01,
+                        double s02, double s11, double s12, double s22) {
     double bv[RM_ROWS_B];
 #pragma unroll
     for (int c = 0; c < RM_ROWS_B; ++c) bv[c] = 0.0;
-    const nnkey_t key = kahead[r];
-    const float d2 = __uint_as_float((unsigned)(key >> 32));
-    if (key != NNKEY_NONE && (double)d2 < corr_dist2) {  // gicp.hpp:483
-      const int j = (int)(key & 0xFFFFFFFFu);
-      const float4 pf = out[i];
-      float4 qf;
-      double s00, s01, s02, s11, s12, s22;  // S = R C1 R^T + C2 (symmetric)
-      if constexpr (COMPACT) {
-        // Compact clouds keep the stored normal instead of the six doubles: 16 bytes read per
-        // source point instead of 48, one 32-byte record gathered per match instead of 64, all
-        // four loads issued together.  With C = 1 - k n n^T (k = 0.999 / |n|^2, see
-        // cov_of_regular_normal) the sum is S = (R R^T + 1) - k1 (R n1)(R n1)^T - k2 n2 n2^T:
-        // the same quantity as R C1 R^T + C2 whatever R is, in a third of the operations.  The
-        // rare points whose normal falls into one of the reference's special branches carry a
-        // flag; a wave that holds one redoes those lanes from the stored matrices (wave-uniform
-        // test, so the common path has no branch between its loads and their use).
-        const float4 n1 = s_cnrm[i];
-        const float4* const tr = t_rec + 2 * (size_t)j;
-        qf = tr[0];
-        const float4 n2 = tr[1];
-        const double n1x = n1.x, n1y = n1.y, n1z = n1.z, n2x = n2.x, n2y = n2.y, n2z = n2.z;
-        const double k1 = 0.999 * fast_rcp(n1x * n1x + n1y * n1y + n1z * n1z);
-        const double k2 = 0.999 * fast_rcp(n2x * n2x + n2y * n2y + n2z * n2z);
-        const double m0 = R[0] * n1x + R[1] * n1y + R[2] * n1z;
-        const double m1 = R[3] * n1x + R[4] * n1y + R[5] * n1z;
-        const double m2 = R[6] * n1x + R[7] * n1y + R[8] * n1z;
-        const double u0 = k1 * m0, u1 = k1 * m1, u2 = k1 * m2;
-        const double v0 = k2 * n2x, v1 = k2 * n2y, v2 = k2 * n2z;
-        s00 = (G[0] - u0 * m0) - v0 * n2x;
-        s01 = (G[1] - u0 * m1) - v0 * n2y;
-        s02 = (G[2] - u0 * m2) - v0 * n2z;
-        s11 = (G[3] - u1 * m1) - v1 * n2y;
-        s12 = (G[4] - u1 * m2) - v1 * n2z;
-        s22 = (G[5] - u2 * m2) - v2 * n2z;
-        if (__builtin_expect(__ballot(n1.w != 0.f || n2.w != 0.f) != 0, 0)) {
-          if (n1.w != 0.f || n2.w != 0.f) {
-            double c1[6], c2[6];
-            if (n1.w != 0.f) load_cov6(s_cov + 6 * (size_t)i, c1); else cov_of_regular_normal(n1, c1);
-            if (n2.w != 0.f) load_cov6(t_cov + 6 * (size_t)j, c2); else cov_of_regular_normal(n2, c2);
-            sandwich(R, c1, c2, s00, s01, s02, s11, s12, s22);
-          }
-        }
-      } else {
-        // the matched target's point and covariance sit in one 64-byte record: one cache line
-        const float4* const tr = t_rec + 4 * (size_t)j;
-        qf = tr[0];
-        double c1[6], c2[6];
-        load_cov6(s_cov + 6 * (size_t)i, c1);
-        load_cov6(reinterpret_cast<const double*>(tr + 1), c2);
-        sandwich(R, c1, c2, s00, s01, s02, s11, s12, s22);
-      }
+    if (valid) {
       // M = S^-1 by cofactors (Eigen's 3x3 inverse, gicp.hpp:493)
       const double k00 = s11 * s22 - s12 * s12;
       const double k01 = s02 * s12 - s01 * s22;
@@ -255,7 +194,117 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
     // the next round's stores must not overtake these reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-   }
+  };
+
+  // The matches of several rounds are fetched ahead: a round then waits for one memory latency
+  // (its gathers) instead of two in a row (match, then gathers).
+  constexpr int AHEAD = 4;
+  const int first = i0 + wave * 64;
+  if constexpr (COMPACT) {
+    // Compact clouds keep the stored normal instead of the six doubles: 16 bytes read per source
+    // point instead of 48, one 32-byte record gathered per match instead of 64.  With
+    // C = 1 - k n n^T (k = 0.999 / |n|^2, see cov_of_regular_normal) the sum is
+    // S = (R R^T + 1) - k1 (R n1)(R n1)^T - k2 n2 n2^T: the same quantity as R C1 R^T + C2 whatever
+    // R is, in a third of the operations.  The rare points whose normal falls into one of the
+    // reference's special branches carry a flag; a wave that holds one redoes those lanes from
+    // the stored matrices (wave-uniform test, so the common path has no branch between its loads
+    // and their use).
+    // The loop is pipelined by hand: the four gathers of a round are issued before the round
+    // ahead of it computes (a round is one memory round trip of 1-2 us under load followed by
+    // ~0.4 us of arithmetic; with one round in flight the two overlap), the matches AHEAD rounds
+    // before they are needed.
+    struct Gathered {
+      float4 pf, n1, qf, n2;
+      int i, j;
+      bool valid;
+    };
+    auto gather = [&](nnkey_t key, int i) {
+      Gathered g;
+      const float d2 = __uint_as_float((unsigned)(key >> 32));
+      g.valid = key != NNKEY_NONE && (double)d2 < corr_dist2;  // gicp.hpp:483
+      g.i = i, g.j = (int)(key & 0xFFFFFFFFu);
+      g.pf = g.n1 = g.qf = g.n2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.valid) {
+        const float4* const tr = t_rec + 2 * (size_t)g.j;
+        g.pf = out[i], g.n1 = s_cnrm[i], g.qf = tr[0], g.n2 = tr[1];
+      }
+      return g;
+    };
+    nnkey_t kq[AHEAD];
+#pragma unroll
+    for (int r = 0; r < AHEAD; ++r) {
+      const int i = first + r * RED_THREADS + lane;
+      kq[r] = i < i1 ? keys[i] : NNKEY_NONE;
+    }
+    Gathered cur = gather(kq[0], first + lane);
+    for (int base = first; base < i1; base += RED_THREADS) {  // wave-uniform
+      const Gathered nxt = gather(kq[1], base + RED_THREADS + lane);
+#pragma unroll
+      for (int r = 0; r + 1 < AHEAD; ++r) kq[r] = kq[r + 1];
+      {
+        const int i = base + AHEAD * RED_THREADS + lane;
+        kq[AHEAD - 1] = i < i1 ? keys[i] : NNKEY_NONE;
+      }
+      double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+      if (cur.valid) {
+        const float4 n1 = cur.n1, n2 = cur.n2;
+        const double n1x = n1.x, n1y = n1.y, n1z = n1.z, n2x = n2.x, n2y = n2.y, n2z = n2.z;
+        const double k1 = 0.999 * fast_rcp(n1x * n1x + n1y * n1y + n1z * n1z);
+        const double k2 = 0.999 * fast_rcp(n2x * n2x + n2y * n2y + n2z * n2z);
+        const double m0 = R[0] * n1x + R[1] * n1y + R[2] * n1z;
+        const double m1 = R[3] * n1x + R[4] * n1y + R[5] * n1z;
+        const double m2 = R[6] * n1x + R[7] * n1y + R[8] * n1z;
+        const double u0 = k1 * m0, u1 = k1 * m1, u2 = k1 * m2;
+        const double v0 = k2 * n2x, v1 = k2 * n2y, v2 = k2 * n2z;
+        s00 = (G[0] - u0 * m0) - v0 * n2x;
+        s01 = (G[1] - u0 * m1) - v0 * n2y;
+        s02 = (G[2] - u0 * m2) - v0 * n2z;
+        s11 = (G[3] - u1 * m1) - v1 * n2y;
+        s12 = (G[4] - u1 * m2) - v1 * n2z;
+        s22 = (G[5] - u2 * m2) - v2 * n2z;
+        if (__builtin_expect(__ballot(n1.w != 0.f || n2.w != 0.f) != 0, 0)) {
+          if (n1.w != 0.f || n2.w != 0.f) {
+            double c1[6], c2[6];
+            if (n1.w != 0.f) load_cov6(s_cov + 6 * (size_t)cur.i, c1); else cov_of_regular_normal(n1, c1);
+            if (n2.w != 0.f) load_cov6(t_cov + 6 * (size_t)cur.j, c2); else cov_of_regular_normal(n2, c2);
+            sandwich(R, c1, c2, s00, s01, s02, s11, s12, s22);
+          }
+        }
+      }
+      accumulate(cur.valid, cur.pf, cur.qf, s00, s01, s02, s11, s12, s22);
+      cur = nxt;
+    }
+  } else {
+    for (int gbase = first; gbase < i1; gbase += AHEAD * RED_THREADS) {  // wave-uniform
+      nnkey_t kahead[AHEAD];
+#pragma unroll
+      for (int r = 0; r < AHEAD; ++r) {
+        const int i = gbase + r * RED_THREADS + lane;
+        kahead[r] = i < i1 ? keys[i] : NNKEY_NONE;
+      }
+#pragma unroll
+      for (int r = 0; r < AHEAD; ++r) {
+        const int base = gbase + r * RED_THREADS;
+        if (base >= i1) break;
+        const int i = base + lane;
+        const nnkey_t key = kahead[r];
+        const float d2 = __uint_as_float((unsigned)(key >> 32));
+        const bool valid = key != NNKEY_NONE && (double)d2 < corr_dist2;  // gicp.hpp:483
+        float4 pf = make_float4(0.f, 0.f, 0.f, 0.f), qf = pf;
+        double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+        if (valid) {
+          // the matched target's point and covariance sit in one 64-byte record: one cache line
+          const float4* const tr = t_rec + 4 * (size_t)(unsigned)(key & 0xFFFFFFFFu);
+          pf = out[i];
+          qf = tr[0];
+          double c1[6], c2[6];
+          load_cov6(s_cov + 6 * (size_t)i, c1);
+          load_cov6(reinterpret_cast<const double*>(tr + 1), c2);
+          sandwich(R, c1, c2, s00, s01, s02, s11, s12, s22);
+        }
+        accumulate(valid, pf, qf, s00, s01, s02, s11, s12, s22);
+      }
+    }
   }
 
   // D[row][col] sits in lane (row & 3) * 16 + col, register row >> 2; each wave parks its D in
@@ -264,8 +313,7 @@ __global__ __launch_bounds__(RED_THREADS) void gicp_reduce_kernel(
 #pragma unroll
   for (int q = 0; q < 4; ++q) sa[q * 64 + lane] = acc[q];
   __syncthreads();
-  if (threadIdx.x < NSTAT) {
-    const int sidx = threadIdx.x;
+  for (int sidx = threadIdx.x; sidx < NSTAT; sidx += RED_THREADS) {
     auto D = [&](int w, int row, int col) {
       return stage[w][(row >> 2) * 64 + (row & 3) * 16 + col];
     };
@@ -734,11 +782,11 @@ hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
 // ComputeICPCovariancePointPoint (loop_closure/src/IcpLoopComputation.cc:770-882) over the
 // aligned points; roll/pitch/yaw are the ZYX Euler angles of the final rotation.
 template <int POINT2POINT>
-__global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
+__global__ __launch_bounds__(POST_THREADS) void post_reduce_kernel(
     const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
     const PairState* __restrict__ st, const int4* __restrict__ bmap,
     double* __restrict__ partials) {
-  __shared__ double sh[RED_THREADS / 64][NPOST];
+  __shared__ double sh[POST_THREADS / 64][NPOST];
   const int4 bm = bmap[blockIdx.x];
   const int pair = bm.x;
   const PairDev& P = pairs[pair];
@@ -780,7 +828,7 @@ __global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
   const int n = P.n_src;
   const int per = (n + bm.z - 1) / bm.z;
   const int i0 = bm.y * per, i1 = min(n, i0 + per);
-  for (int i = i0 + threadIdx.x; i < i1; i += RED_THREADS) {
+  for (int i = i0 + threadIdx.x; i < i1; i += POST_THREADS) {
     const float4 p = SRC.xyz[i];
     const float ax = ((tf[0] * p.x + tf[1] * p.y) + tf[2] * p.z) + tf[3];
     const float ay = ((tf[4] * p.x + tf[5] * p.y) + tf[6] * p.z) + tf[7];
@@ -867,7 +915,7 @@ __global__ __launch_bounds__(RED_THREADS) void post_reduce_kernel(
   if (threadIdx.x < NPOST) {
     double s = 0;
 #pragma unroll
-    for (int w = 0; w < RED_THREADS / 64; ++w) s += sh[w][threadIdx.x];
+    for (int w = 0; w < POST_THREADS / 64; ++w) s += sh[w][threadIdx.x];
     partials[((size_t)pair * RED_MAX_CHUNKS + bm.y) * NPOST + threadIdx.x] = s;
   }
 }
@@ -877,10 +925,10 @@ hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, cons
                               hipStream_t stream) {
   if (n_blocks <= 0) return hipSuccess;
   if (point2point)
-    hipLaunchKernelGGL(post_reduce_kernel<1>, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
+    hipLaunchKernelGGL(post_reduce_kernel<1>, dim3(n_blocks), dim3(POST_THREADS), 0, stream, clouds,
                        pairs, st, bmap, partials);
   else
-    hipLaunchKernelGGL(post_reduce_kernel<0>, dim3(n_blocks), dim3(RED_THREADS), 0, stream, clouds,
+    hipLaunchKernelGGL(post_reduce_kernel<0>, dim3(n_blocks), dim3(POST_THREADS), 0, stream, clouds,
                        pairs, st, bmap, partials);
   return hipGetLastError();
 }

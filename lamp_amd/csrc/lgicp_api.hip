@@ -1072,9 +1072,10 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   for (int p = 0; p < n_pairs; ++p) {
     all_pairs[p] = p;
     const PairDev& pd = h_pairs[p];
-    // slabs of 1024 source points (a function of the pair alone, so that its sums do not depend
-    // on the batch it travels in): short per-lane chains keep the stragglers' iterations short
-    h_ints[p] = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + 1023) / 1024));
+    // slabs of RED_CHUNK_POINTS source points (a function of the pair alone, so that its sums do
+    // not depend on the batch it travels in), one wave each: short chains keep the stragglers'
+    // iterations short
+    h_ints[p] = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + RED_CHUNK_POINTS - 1) / RED_CHUNK_POINTS));
     const int tiles = bp.clouds[bp.pairs[p].tgt_cloud].n_pad / NN_TILE;
     // the exhaustive kernel may split a query tile's target sweep over up to 64 blocks; the pruned
     // kernel has one block per 64 queries

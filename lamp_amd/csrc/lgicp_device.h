@@ -28,8 +28,13 @@ static constexpr int NN_COUNTER_SLOTS = 4096;  // the evaluated-distance counter
 // number of f64 statistics per pair and outer iteration: 10 x 6 second moments
 // sum(u_k u_l M), 4 x 3 first moments sum(u_k M r0), sum(r0^T M r0), correspondence count
 static constexpr int NSTAT = 74;
-static constexpr int RED_THREADS = 256;
+static constexpr int RED_THREADS = 64;    // linearise/reduce: one wave per workgroup (a slab of up to
+                                          // 1024 points each): small workgroups find room beside the
+                                          // lookup kernel's waves when submits run side by side
+static constexpr int POST_THREADS = 256;  // post-alignment reductions
 static constexpr int RED_MAX_CHUNKS = 16;
+static constexpr int RED_CHUNK_POINTS = 1024;  // source points per slab while a cloud has at most
+                                               // RED_MAX_CHUNKS * RED_CHUNK_POINTS points
 
 // fitness sum, count, non-finite flag, 21 unique entries of Ap
 static constexpr int NPOST = 24;
