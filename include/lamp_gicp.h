@@ -225,8 +225,8 @@ int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n, lgicp_re
  * flight adds is that the last outer iterations of one batch -- a handful of pairs, latency-bound
  * -- run beside the full-size launches of the others.  With n lanes every submit works with a
  * share of the context's streams and batch buffers (one stream each from 4 lanes on; measured on
- * 256-pair batches of 16k-point keyframes: 4.4 ms per batch with one submit at a time, 3.4 ms with
- * four in flight, 3.2 ms with six).  lgicp_submit may then be called from n threads at once (more
+ * 256-pair batches of 16k-point keyframes: 4.5 ms per batch with one submit at a time, 3.3 ms with
+ * four in flight, 3.1 ms with six).  lgicp_submit may then be called from n threads at once (more
  * callers wait their turn); registration (lgicp_add_keyframe(s), lgicp_add_pose,
  * lgicp_wait_registered) and lgicp_align wait for the submits in flight and hold new ones off
  * while they run; submits with a feature-based initialisation (FEATURES, TEASERPP) take the whole
