@@ -233,7 +233,7 @@ def main():
                     help="parts of a submit in flight at once (0 = the library's default)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="submits in flight at once, each from its own host thread "
-                         "(lgicp_set_submit_lanes; 0 = 6 for the GICP-only configurations, 1 for C4)")
+                         "(lgicp_set_submit_lanes; 0 = 6 for the GICP-only configurations, 2 for C4)")
     ap.add_argument("--exhaustive", action="store_true",
                     help="use the exhaustive 1-NN kernel instead of the pruned one")
     args = ap.parse_args()
@@ -286,9 +286,9 @@ def main():
 
     ctx = capi.Context(make_config(capi, args, local_rank, args.slots))
     # Steps overlap: the last outer iterations of a batch (a handful of pairs, latency-bound) run
-    # beside the full-size launches of the next ones.  Feature-based initialisations take the whole
-    # context per submit, so C4 stays at one.
-    in_flight = args.in_flight or (1 if args.config == "C4" or args.slots == 1 else 6)
+    # beside the full-size launches of the next ones.  A context with a feature-based initialisation
+    # (C4) takes two submits at a time.
+    in_flight = args.in_flight or (1 if args.slots == 1 else (2 if args.config == "C4" else 6))
     if in_flight > 1:
         in_flight = ctx.set_submit_lanes(in_flight)
 
@@ -439,7 +439,7 @@ def main():
     for i in range(args.warmup):
         step(i)
         progress(f"warm-up {i + 1}/{args.warmup}")
-    serial = None
+    serial = ser_acc = None
     if in_flight > 1:
         # every set of arrays and every lane's buffers sized before the timed region; and, for the
         # record, the same steps one at a time (each submit on one lane's share of the context)
@@ -447,7 +447,8 @@ def main():
         n_ser = max(n_batches, min(args.steps, 8))
         barrier()
         t_ser = time.perf_counter()
-        collect(ctx, n_ser, 0)
+        ser_acc, _, _ = collect(ctx, n_ser, 0)
+        ser_acc["steps"] = n_ser
         barrier()
         serial = (time.perf_counter() - t_ser) / n_ser
     barrier()
@@ -658,6 +659,11 @@ def main():
             k_cl = pmc_kernel(pmc, "lgicp::clique_starts_group_kernel")
             k_hx = pmc_kernel(pmc, "lgicp::core_hindex_group_kernel")
 
+            # with two submits in flight the launch durations of one overlap the other's kernels:
+            # the figures come from the phase that runs the same steps one at a time
+            t_acc = ser_acc if ser_acc is not None else acc
+            t_steps = ser_acc["steps"] if ser_acc is not None else args.steps
+
             def hbm_line(kernel, ms, nbytes, launches, k, note):
                 gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 per = nbytes / max(launches, 1)
@@ -665,13 +671,13 @@ def main():
                         "frac": gbs / HBM_PEAK_GBS, "traffic": k.get("hbm_bytes_per_launch"),
                         "traffic_over_algorithmic": (k["hbm_bytes_per_launch"] / per
                                                      if k.get("hbm_bytes_per_launch") and per else None),
-                        "avg_launch_ms": ms / max(launches, 1), "launches_per_step": launches / args.steps,
-                        "bytes_per_launch": per, "ms_per_step": ms / args.steps, "exclusive": False,
+                        "avg_launch_ms": ms / max(launches, 1), "launches_per_step": launches / t_steps,
+                        "bytes_per_launch": per, "ms_per_step": ms / t_steps, "exclusive": False,
                         "pmc_summary": pmc_file, "note": note}
             out["roofline_gicp_nn"] = out.pop("roofline")
             out["roofline_gicp_reduce"] = out.pop("roofline_reduce")
             out["roofline"] = hbm_line(
-                "lgicp::clique_starts_group_kernel", acc["clique_ms"], acc["clique_bytes"], acc["clique_launches"],
+                "lgicp::clique_starts_group_kernel", t_acc["clique_ms"], t_acc["clique_bytes"], t_acc["clique_launches"],
                 k_cl, "TEASER++ greedy clique search, one wave per start, all pairs of a group per launch. "
                 "algorithmic bytes: one row of the scale-consistency bit matrix (n/8 B) per start and per "
                 "clique member a start tries (device counter); durations by HIP events on the launching "
@@ -680,7 +686,7 @@ def main():
                 "starts, so most of these bytes are served by L2 / Infinity Cache (see traffic); the kernel is "
                 "bound by the chain ballot -> row fetch -> intersect -> count of every step, not by HBM.")
             out["roofline_hindex"] = hbm_line(
-                "lgicp::core_hindex_group_kernel", acc["hindex_ms"], acc["hindex_bytes"], acc["hindex_launches"],
+                "lgicp::core_hindex_group_kernel", t_acc["hindex_ms"], t_acc["hindex_bytes"], t_acc["hindex_launches"],
                 k_hx, "core numbers by H-operator rounds. algorithmic bytes: the bit matrix (n*n/8 B) of every "
                 "graph still iterating, once per round.  Each probe of a vertex's new value re-reads its row and "
                 "compares it against the bit planes of all values in LDS, so the kernel is bound by LDS "

@@ -229,8 +229,9 @@ int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n, lgicp_re
  * four in flight, 3.1 ms with six).  lgicp_submit may then be called from n threads at once (more
  * callers wait their turn); registration (lgicp_add_keyframe(s), lgicp_add_pose,
  * lgicp_wait_registered) and lgicp_align wait for the submits in flight and hold new ones off
- * while they run; submits with a feature-based initialisation (FEATURES, TEASERPP) take the whole
- * context whatever the setting.  The single-operation entry points below (lgicp_nn_search,
+ * while they run.  A context with a feature-based initialisation (FEATURES, TEASERPP) has at most
+ * two lanes (each works with its own set of feature buffers and four streams; 512-pair TEASERPP
+ * batches: 0.65 s per batch in turn, 0.50 s with two in flight).  The single-operation entry points below (lgicp_nn_search,
  * lgicp_fpfh, ...) use the context's first stream and are not to be called while submits are in
  * flight.  Every lane holds its own batch buffers (sized by its largest batch so far, at most
  * workspace_bytes of device memory each).  lgicp_get_stats' "last submit" fields describe

@@ -283,9 +283,10 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __
 namespace lgicp_detail {
 
 
-static MatcherDev& matcher_of(lgicp_ctx* ctx) {
-  if (!ctx->matcher) ctx->matcher = std::make_shared<MatcherDev>();
-  return *ctx->matcher;
+static MatcherDev& matcher_of(lgicp_ctx* ctx, int fset) {
+  if (fset < 0 || fset >= lgicp_ctx::FEATURE_SETS) fset = 0;
+  if (!ctx->matcher[fset]) ctx->matcher[fset] = std::make_shared<MatcherDev>();
+  return *ctx->matcher[fset];
 }
 
 // descriptor k-NN table [n_src][k] (device pointers; partial lists live in `d`)
@@ -320,7 +321,7 @@ int sac_align_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatur
   const int n_src = (int)src.idx.size(), n_tgt = (int)tgt.idx.size();
   if (n_src < 3 || n_tgt < 1) return LGICP_OK;
   const int k = std::min(5, n_tgt);  // setCorrespondenceRandomness(5), IcpLoopComputation.cc:697
-  if (lane < 0 || lane >= FEATURE_LANES || lane >= ctx->n_slots) lane = 0;
+  if (lane < 0 || lane >= lgicp_ctx::FEATURE_SETS * FEATURE_LANES || lane >= ctx->n_slots) lane = 0;
   hipStream_t st = ctx->slot[lane].stream;
   SacLane& d = ctx->sac_lanes.get()[lane];
   MatcherDev& md = d.md;
@@ -404,7 +405,7 @@ void parallel_for(int n, F f) {
 // and keypoints the clouds' features keep there.  Everything is enqueued on the context's stream
 // and the call returns; the matched keypoints land in the job's pinned buffer.
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                          TeaserJob* job, hipStream_t st) {
+                          TeaserJob* job, hipStream_t st, int fset) {
   namespace tz = lgicp::teaser;
   job->n_matches = 0;
   job->src.clear();
@@ -429,7 +430,7 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
   }
   if (!src.d_feat || !tgt.d_feat) return fail(ctx, LGICP_E_INVALID, "cloud features without device copies");
   if (!st) st = ctx->stream;
-  MatcherDev& md = matcher_of(ctx);
+  MatcherDev& md = matcher_of(ctx, fset);
   const tz::Params prm;
   tz::BitGraph& g = job->graph;
   g.n = n;
@@ -487,14 +488,14 @@ void teaser_prepare_collect(TeaserJob* job) {
 // work spread over threads.  T_out[i] is the guess unless the TEASER++
 // transform scores at least as well over the matches.
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
-                        float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times) {
+                        float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times, hipStream_t st) {
   namespace tz = lgicp::teaser;
   for (int i = 0; i < count; ++i) {
     std::memcpy(T_out[i], guesses[i], sizeof(float) * 16);
     used[i] = n_clique[i] = 0;
   }
   const tz::Params prm;
-  hipStream_t st = ctx->stream;
+  if (!st) st = ctx->stream;
   std::vector<std::vector<int>> cliques((size_t)count);
   {
     std::vector<CliqueGraph> graphs((size_t)count, CliqueGraph{nullptr, 0, 0});

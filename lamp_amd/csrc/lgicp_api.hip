@@ -267,9 +267,10 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
     return fail(nullptr, LGICP_E_HIP, "stream / pinned allocation failed");
   }
   ctx->stream = ctx->slot[0].stream;
-  ctx->feature_scratch = std::shared_ptr<FeatureScratch>(new FeatureScratch[FEATURE_LANES],
+  ctx->feature_scratch = std::shared_ptr<FeatureScratch>(new FeatureScratch[lgicp_ctx::FEATURE_SETS * FEATURE_LANES],
                                                          std::default_delete<FeatureScratch[]>());
-  ctx->sac_lanes = std::shared_ptr<SacLane>(new SacLane[FEATURE_LANES], std::default_delete<SacLane[]>());
+  ctx->sac_lanes = std::shared_ptr<SacLane>(new SacLane[lgicp_ctx::FEATURE_SETS * FEATURE_LANES],
+                                            std::default_delete<SacLane[]>());
   ctx->helpers[0].start(ctx->n_slots - 1);
   *out = ctx;
   return LGICP_OK;
@@ -283,12 +284,14 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
   for (auto& kv : ctx->scans) kv.second.free_device();
   ctx->reg.destroy();
-  ctx->teaser_slots.clear();  // device buffers: released while the context's device is current
-  if (ctx->matcher) ctx->matcher->release();
+  for (int f = 0; f < lgicp_ctx::FEATURE_SETS; ++f) {
+    ctx->teaser_slots[f].clear();  // device buffers: released while the context's device is current
+    if (ctx->matcher[f]) ctx->matcher[f]->release();
+  }
   if (ctx->feature_scratch)
-    for (int l = 0; l < FEATURE_LANES; ++l) ctx->feature_scratch.get()[l].release();
+    for (int l = 0; l < lgicp_ctx::FEATURE_SETS * FEATURE_LANES; ++l) ctx->feature_scratch.get()[l].release();
   if (ctx->sac_lanes)
-    for (int l = 0; l < FEATURE_LANES; ++l) ctx->sac_lanes.get()[l].release();
+    for (int l = 0; l < lgicp_ctx::FEATURE_SETS * FEATURE_LANES; ++l) ctx->sac_lanes.get()[l].release();
   delete ctx;
 }
 
@@ -408,12 +411,18 @@ int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes) {
   std::unique_lock<std::shared_mutex> data(ctx->data_mu);
   AllLanes all(ctx);
   lanes = std::min<int>(lanes, lgicp_ctx::MAX_LANES);
+  const bool feature_init = ctx->cfg.init_method == LGICP_INIT_FEATURES ||
+                            ctx->cfg.init_method == LGICP_INIT_TEASERPP;
+  // a feature-based initialisation works with one of the context's sets of feature buffers and the
+  // four streams that go with it
+  if (feature_init) lanes = std::min<int>(lanes, lgicp_ctx::FEATURE_SETS);
+  const int want_slots = feature_init && lanes > 1 ? FEATURE_LANES * lanes : lanes;
   // More lanes than the context has slots: further slots on streams of their own.  They share the
   // process's hardware queues with the first ones, which is what is wanted here (a lane's work is
   // a chain of dependent launches with host round trips in between; a queue serves another lane
   // meanwhile); one submit is never spread over them.
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-  while (ctx->n_slots < lanes) {
+  while (ctx->n_slots < want_slots) {
     hipStream_t s = nullptr;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     if (!ctx->slot[ctx->n_slots].create(s)) {
@@ -424,7 +433,7 @@ int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes) {
   }
   for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->helpers[l].shutdown();
   ctx->n_lanes = lanes;
-  for (int l = 0; l < lanes; ++l) ctx->helpers[l].start(ctx->n_slots / lanes - 1);
+  for (int l = 0; l < lanes; ++l) ctx->helpers[l].start(feature_init ? 0 : ctx->n_slots / lanes - 1);
   return lanes;
 }
 
@@ -675,9 +684,15 @@ void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t
 int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vector<CloudDev>& h_clouds,
                              const lgicp_candidate* cand, lgicp_result* out,
                              std::vector<PairDev>& h_pairs, std::vector<PairState>& h_state,
-                             std::vector<char>& init_rejected, lgicp_stats& stats) {
+                             std::vector<char>& init_rejected, lgicp_stats& stats, int fset) {
   const lgicp_config& cfg = ctx->cfg;
   const int n_pairs = (int)bp.pairs.size();
+  if (fset < 0 || fset >= lgicp_ctx::FEATURE_SETS || ctx->n_slots < FEATURE_LANES * (fset + 1)) fset = 0;
+  const int lane0 = FEATURE_LANES * fset;  // this set's streams: slots lane0 .. lane0 + 3
+  hipStream_t main_stream = ctx->slot[lane0 < ctx->n_slots ? lane0 : 0].stream;
+  // Keyframes keep their features: the look-up and the computation of the missing ones belong to
+  // one submit at a time (a second one waits here, then finds them)
+  std::unique_lock<std::mutex> feat_lock(ctx->feat_mu);
   std::map<int, std::shared_ptr<CloudFeatures>> feat_ptr;
   std::vector<int> todo;  // clouds whose features have to be computed
   for (int p = 0; p < n_pairs; ++p)
@@ -707,7 +722,7 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
         if (q >= todo.size() || rc_all.load() != LGICP_OK) return;
         const int c = todo[q];
         const int rc = compute_cloud_features(ctx, h_clouds[c].xyz, h_clouds[c].nrm_x, h_clouds[c].n,
-                                              feat_ptr[c].get(), lane);
+                                              feat_ptr[c].get(), lane0 + lane);
         if (rc != LGICP_OK) rc_all.store(rc);
       }
     };
@@ -723,6 +738,7 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
       return rc_all.load();
     }
   }
+  feat_lock.unlock();
   struct FeatView {  // feats[c] as before
     std::map<int, std::shared_ptr<CloudFeatures>>& m;
     const CloudFeatures& operator[](int c) const { return *m.at(c); }
@@ -740,9 +756,9 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     // Two sets of slots: while the clique search of one group runs on the context's stream (chains
     // of launches that leave much of the GPU idle in their tails), a helper thread enqueues the
     // matches and graphs of the next group on a second stream.
-    std::vector<std::shared_ptr<TeaserJob>>& slots = ctx->teaser_slots;
+    std::vector<std::shared_ptr<TeaserJob>>& slots = ctx->teaser_slots[fset];
     while ((int)slots.size() < 2 * kGroup) slots.push_back(std::make_shared<TeaserJob>());
-    hipStream_t prep_stream = ctx->n_slots >= 2 ? ctx->slot[1].stream : ctx->stream;
+    hipStream_t prep_stream = ctx->n_slots >= lane0 + 2 ? ctx->slot[lane0 + 1].stream : main_stream;
     std::vector<int> by_size((size_t)n_pairs);
     for (int p = 0; p < n_pairs; ++p) by_size[p] = p;
     std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) {
@@ -768,7 +784,7 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
         const int p = by_size[q++];
         const PairPlan& pp = bp.pairs[p];
         TeaserJob* job = slots[(size_t)half * kGroup + G.count].get();
-        G.rc = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], job, prep_stream);
+        G.rc = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], job, prep_stream, fset);
         if (G.rc != LGICP_OK) return;
         bytes += (size_t)job->graph.n * job->graph.words * sizeof(uint64_t);
         G.pair[G.count] = p, G.jobs[G.count] = job, G.guesses[G.count] = pp.guess;
@@ -794,7 +810,7 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
       float T0[kGroup][16];
       int used[kGroup], nc[kGroup];
       CliqueTimes ct;
-      const int rc = teaser_finish_group(ctx, cur->jobs, cur->guesses, g, T0, used, nc, &ct);
+      const int rc = teaser_finish_group(ctx, cur->jobs, cur->guesses, g, T0, used, nc, &ct, main_stream);
       if (helper.joinable()) helper.join();
       stats.clique_ms += ct.starts_ms, stats.clique_row_bytes += ct.starts_row_bytes;
       stats.clique_launches += ct.starts_launches;
@@ -839,7 +855,7 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
         const uint32_t seed = 0x5AC1A000u ^ (uint32_t)(cand[pp.cand].key_from * 2654435761ull) ^
                               (uint32_t)(cand[pp.cand].key_to * 40503ull);
         const int rc = sac_align_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], pp.guess, seed, T0,
-                                        &score, lane);
+                                        &score, lane0 + lane);
         if (rc != LGICP_OK) {
           rc_all.store(rc);
           return;
@@ -1182,7 +1198,8 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   std::vector<char> init_rejected((size_t)n_pairs, 0);
   if (!explicit_guess &&
       (cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP)) {
-    const int rc = initialise_from_features(ctx, bp, h_clouds, cand, out, h_pairs, h_state, init_rejected, W->stats);
+    const int rc = initialise_from_features(ctx, bp, h_clouds, cand, out, h_pairs, h_state, init_rejected, W->stats,
+                                            (int)(W - ctx->slot) / FEATURE_LANES);
     if (rc != LGICP_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(d_pairs, h_pairs.data(), sizeof(PairDev) * n_pairs,
                                 hipMemcpyHostToDevice, st));
@@ -1493,15 +1510,16 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   };
   HIP_TRY(ctx, hipSetDevice(cfg.device));
   // Keyframes and poses stay put for the duration (registration waits).  A submit runs on one lane
-  // of the context; the feature-based initialisations use buffers and streams the context has
-  // once and take all of it.
+  // of the context.
   std::shared_lock<std::shared_mutex> data(ctx->data_mu);
-  const bool whole_context = cfg.init_method == LGICP_INIT_FEATURES ||
-                             cfg.init_method == LGICP_INIT_TEASERPP || ctx->n_lanes == 1;
+  // (a context with a feature-based initialisation has at most two lanes, each with one of the
+  // context's two sets of feature buffers and four streams, see lgicp_set_submit_lanes)
+  const bool feature_init = cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP;
+  const bool whole_context = ctx->n_lanes == 1;
   std::unique_ptr<AllLanes> hold_all(whole_context ? new AllLanes(ctx) : nullptr);
   std::unique_ptr<OneLane> hold_one(whole_context ? nullptr : new OneLane(ctx));
   const int lane = hold_one ? hold_one->lane : 0;
-  const int lane_slots = hold_one ? ctx->n_slots / ctx->n_lanes : ctx->n_wide;
+  const int lane_slots = hold_one ? (feature_init ? FEATURE_LANES : ctx->n_slots / ctx->n_lanes) : ctx->n_wide;
   const int first_slot = lane * lane_slots;
   // with several lanes configured lane 0's helpers serve fewer slots than a whole-context
   // submit could use: it runs on the slots they cover

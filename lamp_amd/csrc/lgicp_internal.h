@@ -297,11 +297,16 @@ struct lgicp_ctx {
   mutable std::mutex stats_mu;
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points
   Registry reg;                  // keyframe registration
+  // Working state of the feature-based initialisations, FEATURE_SETS copies of it: a FEATURES /
+  // TEASERPP submit works with one set (set f runs on the streams of slots 4 f .. 4 f + 3), so two
+  // such submits can run side by side.
+  static constexpr int FEATURE_SETS = 2;
   // bit matrices and matches of the pairs of a TEASERPP group, reused from submit to submit
-  std::vector<std::shared_ptr<lgicp_detail::TeaserJob>> teaser_slots;
-  std::shared_ptr<lgicp_detail::MatcherDev> matcher;
-  std::shared_ptr<lgicp_detail::FeatureScratch> feature_scratch;  // [FEATURE_LANES]
-  std::shared_ptr<lgicp_detail::SacLane> sac_lanes;               // [FEATURE_LANES]
+  std::vector<std::shared_ptr<lgicp_detail::TeaserJob>> teaser_slots[FEATURE_SETS];
+  std::shared_ptr<lgicp_detail::MatcherDev> matcher[FEATURE_SETS];
+  std::shared_ptr<lgicp_detail::FeatureScratch> feature_scratch;  // [FEATURE_SETS * FEATURE_LANES]
+  std::shared_ptr<lgicp_detail::SacLane> sac_lanes;               // [FEATURE_SETS * FEATURE_LANES]
+  std::mutex feat_mu;  // Keyframe::features: looked up and filled by one submit at a time
 };
 
 namespace lgicp_detail {
@@ -325,7 +330,8 @@ struct CloudFeatures {
 int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe* out, bool derive);
 int flush_registrations(lgicp_ctx* ctx);
 // `lane` selects the stream (the context's batch slot streams) and the scratch buffers: calls
-// with different lanes may run at the same time from different host threads
+// with different lanes may run at the same time from different host threads.  Lanes
+// FEATURE_LANES * f .. FEATURE_LANES * f + 3 belong to feature set f.
 int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_nrm, int n,
                            CloudFeatures* out, int lane = 0);
 // (lane: stream and buffers, as for compute_cloud_features)
@@ -403,11 +409,14 @@ int clique_device_max_vertices();
 // keypoints into job->src / job->dst
 // (st: the stream the work is enqueued on, the context's own when null; one caller at a time, the
 // matcher's buffers are shared)
+// (fset: whose descriptor-matcher buffers the call uses)
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                          TeaserJob* job, hipStream_t st = nullptr);
+                          TeaserJob* job, hipStream_t st = nullptr, int fset = 0);
 void teaser_prepare_collect(TeaserJob* job);
+// (st: the stream of the clique search, the context's own when null)
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
-                        float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times = nullptr);
+                        float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times = nullptr,
+                        hipStream_t st = nullptr);
 
 // device address of the static scratch array behind lgicp_nn_search_static, looked up once per
 // device; `device` must be the current device

@@ -400,7 +400,7 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   if (cfg.harris_response != 1 || cfg.harris_refine || !cfg.harris_suppression)
     return fail(ctx, LGICP_E_UNSUPPORTED,
                 "only the HARRIS response with non-maxima suppression and no refinement is built");
-  if (lane < 0 || lane >= FEATURE_LANES || lane >= ctx->n_slots) lane = 0;
+  if (lane < 0 || lane >= lgicp_ctx::FEATURE_SETS * FEATURE_LANES || lane >= ctx->n_slots) lane = 0;
   hipStream_t st = ctx->slot[lane].stream;
   FeatureScratch& d = ctx->feature_scratch.get()[lane];
   if (d.resp.reserve((size_t)n) != hipSuccess || d.key.reserve((size_t)n) != hipSuccess)

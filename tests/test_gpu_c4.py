@@ -136,3 +136,56 @@ def test_c4_group_results_do_not_depend_on_the_grouping():
         assert a["init_fitness"] == b["init_fitness"]
         assert np.array_equal(a["T_init"], b["T_init"])
         assert np.array_equal(a["T_icp"], b["T_icp"]) and a["status"] == b["status"]
+
+
+@pytest.mark.parametrize("method", ["TEASERPP", "FEATURES"])
+def test_c4_submits_side_by_side_equal_submits_in_turn(method):
+    """A context with a feature-based initialisation takes two submits at a time
+    (lgicp_set_submit_lanes: each works with its own set of feature buffers and streams).  Three
+    threads, each with its own batch over keyframes the batches share, the first submits computing
+    the keyframes' features: every result equals the one the batch got when submitted alone."""
+    import threading
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=36, keyframes=8, points=8192)
+    cands = work.candidates()
+    batches = [cands[0:12], cands[12:24], cands[24:36]]
+
+    def dicts(res):
+        return [capi.result_to_dict(r) for r in res]
+
+    def make():
+        c = capi.Context(init_method=getattr(capi, "INIT_" + method), harris_radius=0.4,
+                         transform_thresholding=0)
+        work.register(c)
+        return c
+
+    ref_ctx = make()
+    try:
+        ref = [dicts(ref_ctx.submit(b)) for b in batches]
+    finally:
+        ref_ctx.close()
+    c = make()                       # fresh: no keyframe has features yet
+    try:
+        assert c.set_submit_lanes(4) == 2
+        got, errors = [None] * 3, []
+
+        def run(k):
+            try:
+                for _ in range(2):
+                    got[k] = dicts(c.submit(batches[k]))
+            except Exception as e:   # noqa: BLE001 - reported by the main thread
+                errors.append(e)
+
+        th = [threading.Thread(target=run, args=(k,)) for k in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+    finally:
+        c.close()
+    for a_list, b_list in zip(ref, got):
+        for a, b in zip(a_list, b_list):
+            assert a["status"] == b["status"] and a["init_fitness"] == b["init_fitness"]
+            assert np.array_equal(a["T_init"], b["T_init"]) and np.array_equal(a["T_icp"], b["T_icp"])
