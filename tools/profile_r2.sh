@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02_$CFG
 rm -rf $O; mkdir -p $O
 STEPS=8; WARM=4; FULL=""; PT=120
-if [ "$CFG" = "C4" ]; then STEPS=2; WARM=1; FULL="--steps 3 --warmup 1 --cpu-sample 16"; PT=280; fi
+if [ "$CFG" = "C4" ]; then STEPS=2; WARM=1; FULL="--steps 6 --warmup 2 --cpu-sample 16"; PT=280; fi
 ONE="--config $CFG --slots 1 --steps $STEPS --warmup $WARM --no-cpu --no-exclusive-phase --no-cold"
 timeout -k 10 580 python3 bench.py --config $CFG $FULL > $O/bench.json 2> $O/bench.err
 timeout -k 10 280 python3 bench.py $ONE > $O/bench_one_stream.json 2> $O/bench_one_stream.err
