@@ -401,6 +401,7 @@ extern "C" {
 int lgicp_add_keyframes(lgicp_ctx* ctx, size_t count, const uint64_t* keys, const float* const* xyz,
                         const float* const* normals, const size_t* n_points, size_t stride_bytes) {
   if (!ctx) return LGICP_E_INVALID;
+  std::lock_guard<std::mutex> gate(ctx->gate_mu);
   std::unique_lock<std::shared_mutex> data(ctx->data_mu);  // waits for submits in flight
   return add_keyframes_locked(ctx, count, keys, xyz, normals, n_points, stride_bytes);
 }
@@ -408,6 +409,7 @@ int lgicp_add_keyframes(lgicp_ctx* ctx, size_t count, const uint64_t* keys, cons
 int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes) {
   if (!ctx) return LGICP_E_INVALID;
   if (lanes < 1) return fail(ctx, LGICP_E_INVALID, "lanes must be >= 1");
+  std::lock_guard<std::mutex> gate(ctx->gate_mu);
   std::unique_lock<std::shared_mutex> data(ctx->data_mu);
   AllLanes all(ctx);
   lanes = std::min<int>(lanes, lgicp_ctx::MAX_LANES);
@@ -444,6 +446,7 @@ int lgicp_add_keyframe(lgicp_ctx* ctx, uint64_t key, const float* xyz, const flo
 
 int lgicp_wait_registered(lgicp_ctx* ctx) {
   if (!ctx) return LGICP_E_INVALID;
+  std::lock_guard<std::mutex> gate(ctx->gate_mu);
   std::unique_lock<std::shared_mutex> data(ctx->data_mu);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   const int rc = flush_registrations(ctx);
@@ -454,6 +457,7 @@ int lgicp_wait_registered(lgicp_ctx* ctx) {
 
 int lgicp_add_pose(lgicp_ctx* ctx, uint64_t key, const double q[4], const double t[3]) {
   if (!ctx || !q || !t) return LGICP_E_INVALID;
+  std::lock_guard<std::mutex> gate(ctx->gate_mu);
   std::unique_lock<std::shared_mutex> data(ctx->data_mu);
   if (ctx->poses.count(key)) return 0;  // first wins (IcpLoopComputation.cc:400-402)
   ctx->poses.emplace(key, hm::pose_from_quat(q, t));
@@ -1511,7 +1515,11 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   HIP_TRY(ctx, hipSetDevice(cfg.device));
   // Keyframes and poses stay put for the duration (registration waits).  A submit runs on one lane
   // of the context.
-  std::shared_lock<std::shared_mutex> data(ctx->data_mu);
+  std::shared_lock<std::shared_mutex> data(ctx->data_mu, std::defer_lock);
+  {
+    std::lock_guard<std::mutex> gate(ctx->gate_mu);  // behind any registration that is waiting
+    data.lock();
+  }
   // (a context with a feature-based initialisation has at most two lanes, each with one of the
   // context's two sets of feature buffers and four streams, see lgicp_set_submit_lanes)
   const bool feature_init = cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP;
@@ -1658,6 +1666,7 @@ extern "C" int lgicp_align(lgicp_ctx* ctx, const float* src_xyz, const float* sr
   if (!ctx || !guess || !final_T) return fail(ctx, LGICP_E_INVALID, "null argument");
   if (n_src == 0 || n_tgt == 0) return fail(ctx, LGICP_E_INVALID, "empty cloud");
   const uint64_t ks = 0xFFFFFFF000000000ull, kt = 0xFFFFFFE000000000ull;
+  std::lock_guard<std::mutex> gate(ctx->gate_mu);
   std::unique_lock<std::shared_mutex> data(ctx->data_mu);  // adds and removes two keyframes
   AllLanes all(ctx);
   if (ctx->scans.count(ks) || ctx->scans.count(kt))

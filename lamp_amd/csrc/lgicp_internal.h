@@ -293,6 +293,11 @@ struct lgicp_ctx {
   bool lane_busy[MAX_LANES] = {};
   // keyframes and poses: submits read them (shared), registration and lgicp_align change them
   mutable std::shared_mutex data_mu;
+  // Writers hold this while they wait for and hold data_mu, submits pass through it before they
+  // take data_mu shared: a registration that has arrived goes before the submits that arrive
+  // after it (the shared mutex alone prefers readers, and submits from several threads overlap
+  // without a gap for as long as there is work).
+  std::mutex gate_mu;
   std::mutex flush_mu;  // flush_registrations: one submit at a time
   mutable std::mutex stats_mu;
   hipStream_t stream = nullptr;  // = slot[0].stream: registration and the single-kernel entry points

@@ -163,6 +163,53 @@ def test_submits_side_by_side_equal_submits_in_turn(lanes, threads):
         c.close()
 
 
+def test_registration_is_not_starved_by_overlapping_submits():
+    """Six threads submit without a pause; a registration that arrives meanwhile goes ahead of the
+    submits that arrive after it instead of waiting for a gap that never comes."""
+    import threading
+    import time
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    works = [Workload("C2", pairs=48, points=4096, keyframes=8, shard=s, key_offset=100000 * s)
+             for s in range(6)]
+    late = Workload("C2", pairs=8, points=4096, keyframes=4, shard=17, key_offset=9000000)
+    c = capi.Context(init_method=capi.INIT_IDENTITY)
+    try:
+        for w in works:
+            w.register(c)
+        assert c.set_submit_lanes(6) == 6
+        stop, errors, counts = threading.Event(), [], [0] * 6
+
+        def submitter(k):
+            try:
+                pk = c.pack_candidates(works[k].candidates())
+                while not stop.is_set():
+                    c.submit_packed(pk)
+                    counts[k] += 1
+            except Exception as e:   # noqa: BLE001 - reported by the main thread
+                errors.append(e)
+
+        th = [threading.Thread(target=submitter, args=(k,)) for k in range(6)]
+        for t in th:
+            t.start()
+        time.sleep(0.3)
+        before = sum(counts)
+        t0 = time.perf_counter()
+        late.register(c)
+        waited = time.perf_counter() - t0
+        time.sleep(0.2)
+        stop.set()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        assert before > 0 and sum(counts) > before     # submits ran before and after it
+        assert waited < 1.0, waited
+        res = c.submit(late.candidates())
+        assert sum(r.status == 0 for r in res) >= 6
+    finally:
+        c.close()
+
+
 def test_small_workspace_cuts_the_submit_into_sub_batches():
     """workspace_bytes bounds the per-batch scratch (configuration C5 does not fit one batch):
     the results do not depend on where the cuts fall."""
