@@ -296,7 +296,12 @@ void lgicp_destroy(lgicp_ctx* ctx) {
 }
 
 const char* lgicp_last_error(const lgicp_ctx* ctx) {
-  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+  if (!ctx) return g_create_error.c_str();
+  // a copy per calling thread: submits of other threads may set a new message meanwhile
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lock(const_cast<lgicp_ctx*>(ctx)->err_mu);
+  copy = ctx->err;
+  return copy.c_str();
 }
 
 }  // extern "C"
