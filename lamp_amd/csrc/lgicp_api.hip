@@ -1057,6 +1057,12 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     }
   }
 
+  // the arena was sized from the plan's estimate before anything was carved out of it: nothing
+  // may have been handed out past its end
+  if (ar.off > W->arena.cap)
+    return fail(ctx, LGICP_E_NOMEM, "batch scratch estimate too small (%zu bytes needed, %zu reserved)",
+                ar.off, W->arena.cap);
+
   // ---- block maps ----------------------------------------------------------------------------
   // Rebuilt whenever pairs drop out of the outer loop: the 1-NN grid covers the active pairs
   // only, and when few are left their targets are split over several workgroups so that the
