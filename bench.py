@@ -189,6 +189,50 @@ def cpu_baseline(work, n_sample, cores):
     }
 
 
+def run_steps_in_flight(n_steps, first, depth, submit_step, on_result):
+    """Steps first .. first + n_steps - 1 with `depth` of them in flight: lane k (a thread of its
+    own) runs submit_step(k, i) for i = first + k, first + k + depth, ... without waiting for the
+    other lanes; on_result(i, value) is called on the calling thread in step order (with several
+    ranks the gather behind it is a collective: every rank must issue them in the same order).  An
+    exception in a lane ends the run and is raised here."""
+    import threading
+    done, cv, failed = {}, threading.Condition(), []
+
+    def lane_loop(k):
+        try:
+            for i in range(first + k, first + n_steps, depth):
+                value = submit_step(k, i)
+                with cv:
+                    if failed:
+                        return
+                    done[i] = value
+                    cv.notify_all()
+        except Exception as e:   # noqa: BLE001 - raised again by the calling thread
+            with cv:
+                failed.append(e)
+                cv.notify_all()
+
+    threads = [threading.Thread(target=lane_loop, args=(k,)) for k in range(depth)]
+    for t in threads:
+        t.start()
+    try:
+        for i in range(first, first + n_steps):
+            with cv:
+                cv.wait_for(lambda: i in done or failed)
+                if failed:
+                    break
+                value = done.pop(i)
+            on_result(i, value)
+    except Exception as e:       # noqa: BLE001 - the lanes are told to stop, then it is raised
+        with cv:
+            failed.append(e)
+    finally:
+        for t in threads:
+            t.join()
+    if failed:
+        raise failed[0]
+
+
 def make_config(capi, args, local_rank, slots=0):
     if args.config == "C4":
         cfg = capi.default_config(True, device=local_rank,
@@ -345,39 +389,21 @@ def main():
         reports as "last submit" when a step returns: with submits side by side that is now and
         then the neighbour's, so the sums are indicative; the launch and distance counters are
         exact differences over the region."""
-        import threading
         acc = dict(nn_ms=0.0, nn_launches=0.0, nn_evals=0.0, nn_exec=0.0, red_ms=0.0,
                    red_launches=0.0, red_points=0.0, red_inliers=0.0, cycle_exits=0.0,
                    clique_ms=0.0, clique_bytes=0.0, clique_launches=0.0,
                    hindex_ms=0.0, hindex_bytes=0.0, hindex_launches=0.0)
         stage = dict(nn=0.0, reduce=0.0, solve=0.0, cov=0.0, post=0.0, total=0.0)
         s_begin = ctx.stats()
-        done, cv, failed = {}, threading.Condition(), []
-
-        def lane_loop(k):
-            # steps first + k, first + k + depth, ...: a lane never waits for the others
-            try:
-                for i in range(first + k, first + n_steps, depth):
-                    out = ctx.submit_packed(packed_sets[k][i % n_batches])
-                    rec = pack_results(out, len(cand_lists[i % n_batches])) if dist is not None else None
-                    with cv:
-                        done[i] = (out, rec, ctx.stats())
-                        cv.notify_all()
-            except Exception as e:   # noqa: BLE001 - raised again by the main thread
-                with cv:
-                    failed.append(e)
-                    cv.notify_all()
-
-        threads = [threading.Thread(target=lane_loop, args=(k,)) for k in range(depth)]
-        for t in threads:
-            t.start()
         res = []
-        for i in range(first, first + n_steps):   # results in step order (the gather is a collective)
-            with cv:
-                cv.wait_for(lambda: i in done or failed)
-                if failed:
-                    break
-                out, rec, s1 = done.pop(i)
+
+        def submit_step(k, i):
+            out = ctx.submit_packed(packed_sets[k][i % n_batches])
+            rec = pack_results(out, len(cand_lists[i % n_batches])) if dist is not None else None
+            return out, rec, ctx.stats()
+
+        def on_result(i, value):
+            out, rec, s1 = value
             if rec is not None:
                 import torch
                 gatherer.gather(rec)
@@ -394,10 +420,8 @@ def main():
             acc["cycle_exits"] += s1.cycle_exits
             for k in stage:
                 stage[k] += getattr(s1, k + "_ms")
-        for t in threads:
-            t.join()
-        if failed:
-            raise failed[0]
+
+        run_steps_in_flight(n_steps, first, depth, submit_step, on_result)
         s_end = ctx.stats()
         acc["nn_launches"] = s_end.nn_launches - s_begin.nn_launches
         acc["nn_evals"] = s_end.nn_distance_evals - s_begin.nn_distance_evals

@@ -60,3 +60,52 @@ def test_pmc_summary_tool_classifies_lookup_passes(tmp_path):
     assert abs(sweep["valu_issue_utilisation"] - 4 * 2000.0 * 1000.0 / (1024 * 100000.0)) < 1e-12
     assert abs(cert["valu_issue_utilisation"] - 4 * 100.0 * 1000.0 / (1024 * 100000.0)) < 1e-12
     assert s["kernels"]["lgicp::nn_pruned_kernel"]["SQ_WAVES"]["launches"] == 2
+
+
+def test_steps_in_flight_run_once_each_and_report_in_order():
+    """bench.run_steps_in_flight: every step runs exactly once, on the lane its index belongs to;
+    results are handed over in step order whatever order the lanes finish in; `depth` steps really
+    are in flight together; an exception in a lane or in the consumer ends the run and is raised."""
+    import threading
+    import time
+    b = _bench()
+    ran, seen = [], []
+    lock = threading.Lock()
+    in_flight, peak = [0], [0]
+
+    def submit_step(k, i):
+        with lock:
+            in_flight[0] += 1
+            peak[0] = max(peak[0], in_flight[0])
+        time.sleep(0.002 * ((i * 7) % 5))      # lanes finish out of order
+        with lock:
+            in_flight[0] -= 1
+            ran.append((k, i))
+        return i * i
+
+    b.run_steps_in_flight(23, 4, 3, submit_step, lambda i, v: seen.append((i, v)))
+    assert seen == [(i, i * i) for i in range(4, 27)]
+    assert sorted(i for _, i in ran) == list(range(4, 27))
+    assert all(k == (i - 4) % 3 for k, i in ran)
+    assert peak[0] == 3
+
+    def failing(k, i):
+        if i == 9:
+            raise RuntimeError("lane failed")
+        return i
+
+    try:
+        b.run_steps_in_flight(20, 0, 4, failing, lambda i, v: None)
+        raise AssertionError("no exception")
+    except RuntimeError as e:
+        assert "lane failed" in str(e)
+
+    def consumer(i, v):
+        if i == 5:
+            raise ValueError("consumer failed")
+
+    try:
+        b.run_steps_in_flight(12, 0, 2, lambda k, i: i, consumer)
+        raise AssertionError("no exception")
+    except ValueError as e:
+        assert "consumer failed" in str(e)
