@@ -226,8 +226,9 @@ int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n, lgicp_re
  * -- run beside the full-size launches of the others.  With n lanes every submit works with a
  * share of the context's streams and batch buffers (one stream each from 4 lanes on; measured on
  * 256-pair batches of 16k-point keyframes: 4.5 ms per batch with one submit at a time, 3.3 ms with
- * four in flight, 3.1 ms with six).  lgicp_submit may then be called from n threads at once (more
- * callers wait their turn); registration (lgicp_add_keyframe(s), lgicp_add_pose,
+ * four in flight, 3.1 ms with six).  A submit that finds no other submit in flight is spread over
+ * as many streams as with one lane, so a caller that is alone loses nothing by the setting.
+ * lgicp_submit may then be called from n threads at once (more callers wait their turn); registration (lgicp_add_keyframe(s), lgicp_add_pose,
  * lgicp_wait_registered) and lgicp_align wait for the submits in flight and hold new ones off
  * while they run.  A context with a feature-based initialisation (FEATURES, TEASERPP) has at most
  * two lanes (each works with its own set of feature buffers and four streams; 512-pair TEASERPP

@@ -331,11 +331,13 @@ struct AllLanes {
   }
 };
 
-// One lane (or, with a single lane configured, the whole context)
+// One lane of the context -- or, when `wide` lanes from lane 0 on are wanted and no submit is in
+// flight at all, those: a caller that is alone on a context with several lanes gets the width a
+// single submit can use, callers that overlap get one lane each.
 struct OneLane {
   lgicp_ctx* ctx;
-  int lane = 0;
-  explicit OneLane(lgicp_ctx* c) : ctx(c) {
+  int lane = 0, held = 1;
+  OneLane(lgicp_ctx* c, int wide) : ctx(c) {
     std::unique_lock<std::mutex> lk(ctx->lane_mu);
     ctx->lane_cv.wait(lk, [&] {
       for (int l = 0; l < ctx->n_lanes; ++l)
@@ -346,13 +348,17 @@ struct OneLane {
     for (int l = 0; l < ctx->n_lanes; ++l) any_busy = any_busy || ctx->lane_busy[l];
     // outgrown buffers may still be read by what another lane has in flight
     if (!any_busy) free_parked_device_memory();
-    while (ctx->lane_busy[lane]) ++lane;
-    ctx->lane_busy[lane] = true;
+    if (!any_busy && wide > 1) {
+      held = std::min(wide, ctx->n_lanes);
+    } else {
+      while (ctx->lane_busy[lane]) ++lane;
+    }
+    for (int l = lane; l < lane + held; ++l) ctx->lane_busy[l] = true;
   }
   ~OneLane() {
     {
       std::lock_guard<std::mutex> lk(ctx->lane_mu);
-      ctx->lane_busy[lane] = false;
+      for (int l = lane; l < lane + held; ++l) ctx->lane_busy[l] = false;
     }
     ctx->lane_cv.notify_all();
   }
@@ -440,7 +446,9 @@ int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes) {
   }
   for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->helpers[l].shutdown();
   ctx->n_lanes = lanes;
-  for (int l = 0; l < lanes; ++l) ctx->helpers[l].start(feature_init ? 0 : ctx->n_slots / lanes - 1);
+  // (lane 0's helpers also serve a lone submit that is given several lanes)
+  for (int l = 0; l < lanes; ++l)
+    ctx->helpers[l].start(feature_init ? 0 : std::max(ctx->n_slots / lanes, l == 0 ? ctx->n_wide : 1) - 1);
   return lanes;
 }
 
@@ -1535,14 +1543,17 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
   // context's two sets of feature buffers and four streams, see lgicp_set_submit_lanes)
   const bool feature_init = cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP;
   const bool whole_context = ctx->n_lanes == 1;
+  // slots per lane, and the lanes that cover the slots one submit can be spread over
+  const int per_lane = feature_init ? FEATURE_LANES : std::max(1, ctx->n_slots / ctx->n_lanes);
+  const int wide_lanes = feature_init ? 1 : (ctx->n_wide + per_lane - 1) / per_lane;
   std::unique_ptr<AllLanes> hold_all(whole_context ? new AllLanes(ctx) : nullptr);
-  std::unique_ptr<OneLane> hold_one(whole_context ? nullptr : new OneLane(ctx));
+  std::unique_ptr<OneLane> hold_one(whole_context ? nullptr : new OneLane(ctx, wide_lanes));
   const int lane = hold_one ? hold_one->lane : 0;
-  const int lane_slots = hold_one ? (feature_init ? FEATURE_LANES : ctx->n_slots / ctx->n_lanes) : ctx->n_wide;
-  const int first_slot = lane * lane_slots;
-  // with several lanes configured lane 0's helpers serve fewer slots than a whole-context
-  // submit could use: it runs on the slots they cover
-  const int helper_slots = ctx->n_slots / ctx->n_lanes;
+  const int lane_slots = hold_one ? std::min(per_lane * hold_one->held, std::max(per_lane, ctx->n_wide))
+                                  : ctx->n_wide;
+  const int first_slot = lane * per_lane;
+  // the helper threads of the first lane held run the other parts of this submit
+  const int helper_slots = (int)ctx->helpers[lane].threads.size() + 1;
   {
     // keyframes registered since the last submit: their device work runs on the context's stream
     std::lock_guard<std::mutex> fl(ctx->flush_mu);

@@ -1,12 +1,14 @@
-"""Would TEASER++-initialised submits gain from running side by side?  Two contexts on one GPU,
-each with its own copy of a C4 batch, submitting from two threads, against one context."""
+"""Would TEASER++-initialised submits gain from running side by side?  N contexts on one GPU,
+each with its own C4 batch, submitting from N threads, against the same submits in turn.
+usage: c4_two_context_probe.py [PAIRS [N]]"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from lamp_amd import capi
 from lamp_amd.workload import Workload
 
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-works = [Workload("C4", pairs=n_pairs, shard=s, key_offset=100000 * s) for s in range(2)]
+n_ctx = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+works = [Workload("C4", pairs=n_pairs, shard=s, key_offset=100000 * s) for s in range(n_ctx)]
 
 
 def make(w):
@@ -26,7 +28,7 @@ for c, pk in ctxs:
     for _ in range(K):
         c.submit_packed(pk)
 dt = time.perf_counter() - t0
-print(f"in turn: {1e3 * dt / (2 * K):.1f} ms per batch of {n_pairs}", flush=True)
+print(f"in turn: {1e3 * dt / (n_ctx * K):.1f} ms per batch of {n_pairs}", flush=True)
 
 
 def run(c, pk):
@@ -41,6 +43,6 @@ for t in th:
 for t in th:
     t.join()
 dt = time.perf_counter() - t0
-print(f"side by side: {1e3 * dt / (2 * K):.1f} ms per batch of {n_pairs}", flush=True)
+print(f"{n_ctx} side by side: {1e3 * dt / (n_ctx * K):.1f} ms per batch of {n_pairs}", flush=True)
 for c, _ in ctxs:
     c.close()
