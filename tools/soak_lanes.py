@@ -1,6 +1,7 @@
 """Soak for submits side by side: LANES host threads submit rotating C2 batches N times each on one
 context; every result is compared, bit for bit, with what the same batch returned when it was
-submitted alone.  usage: soak_lanes.py [LANES [N]]"""
+submitted alone.  SOAK_REGISTER=1 adds a thread that keeps registering new keyframes and verifying
+them meanwhile.  usage: soak_lanes.py [LANES [N]]"""
 import os, sys, time, threading
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -37,13 +38,33 @@ def run(k):
         done[k] += 1
 
 
+n_reg = [0]
+
+
+def registrar():
+    """new keyframes every few milliseconds while the lanes are busy, each batch of them verified
+    by a submit of its own (which competes for a lane like any other)"""
+    s = 0
+    while any(d < n_rep for d in done):
+        w = Workload("C2", pairs=8, points=2048, keyframes=4, shard=100 + s, key_offset=10000000 + 1000 * s)
+        w.register(c)
+        res = c.submit(w.candidates())
+        if sum(r.status == 0 for r in res) < 4:
+            bad.append(("late", s, [r.status for r in res]))
+        n_reg[0] += 1
+        s += 1
+        time.sleep(0.003)
+
+
 t0 = time.perf_counter()
 th = [threading.Thread(target=run, args=(k,)) for k in range(lanes)]
+if os.environ.get("SOAK_REGISTER"):
+    th.append(threading.Thread(target=registrar))
 for t in th:
     t.start()
 while any(t.is_alive() for t in th):
     time.sleep(5)
-    print(f"{sum(done)} submits, {len(bad)} mismatches", flush=True)
+    print(f"{sum(done)} submits, {n_reg[0]} registrations, {len(bad)} mismatches", flush=True)
 for t in th:
     t.join()
 dt = time.perf_counter() - t0
