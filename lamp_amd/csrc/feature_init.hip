@@ -293,9 +293,10 @@ static MatcherDev& matcher_of(lgicp_ctx* ctx, int fset) {
 static int launch_feature_knn(lgicp_ctx* ctx, MatcherDev& d, const float* d_sf, int n_src,
                               const float* d_tf, int n_tgt, int k, int* d_nn, hipStream_t st) {
   const int src_blocks = (n_src + 127) / 128;
-  // enough target ranges for ~4 workgroups per CU, each at least four tiles long
+  // enough target ranges for ~4 workgroups per CU, each at least one tile long (a few hundred
+  // descriptors a side: the launch is as long as one workgroup's chain of tiles)
   int n_splits = std::max(1, std::min((1024 + src_blocks - 1) / src_blocks,
-                                      (n_tgt + 4 * lgicp::FK_TILE - 1) / (4 * lgicp::FK_TILE)));
+                                      (n_tgt + lgicp::FK_TILE - 1) / lgicp::FK_TILE));
   int per_split = (n_tgt + n_splits - 1) / n_splits;
   per_split = ((per_split + lgicp::FK_TILE - 1) / lgicp::FK_TILE) * lgicp::FK_TILE;
   n_splits = (n_tgt + per_split - 1) / per_split;
