@@ -314,6 +314,137 @@ __global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* 
   }
 }
 
+// Core numbers by peeling, one workgroup per graph, one lane per 64-bit word of the alive set.
+// Level k takes out every alive vertex whose remaining degree is <= k (its core number is k) and
+// lowers the degree of each alive neighbour by one, until no such vertex is left; then k moves on to
+// the smallest remaining degree.  Which vertices of a level leave first does not matter for the
+// result: core numbers are a property of the graph, equal to the host's bucket peeling entry by entry.
+// A lane keeps the remaining degrees of its 64 vertices in registers as 16 bit planes: "degree <= k"
+// for all 64 is a bit-sliced comparison, and a leaving vertex v lowers the 64 by its row word in one
+// bit-sliced decrement (a borrow rippling up the planes, gone after a few) - no counter per vertex in
+// memory, no atomics per edge, and the row of v is read once, coalesced over the lanes.  The vertices
+// that leave in a step are handed over through a list in LDS (two lists taking turns: one barrier per
+// step).  A graph is a chain of some thousand dependent steps of a microsecond or two, so one graph
+// keeps a few waves busy and the graphs of a group run side by side, one launch for all of them.
+// c: in the degrees, out the core numbers.  steps_out[graph] = steps taken (diagnostics).
+// blockDim.x = 64 * ceil(widest graph's words / 64).
+constexpr int PEEL_LIST = 2048;  // vertices that leave per step at most; the rest of a level waits a step
+constexpr int PEEL_AHEAD = 4;    // rows requested together
+
+__device__ __forceinline__ void peel_decrement(unsigned long long (&pl)[16], unsigned long long m) {
+  unsigned long long borrow = m;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    if (p > 0 && (p & 3) == 0 && __ballot(borrow != 0) == 0) break;  // wave-uniform
+    const unsigned long long t = pl[p];
+    pl[p] = t ^ borrow;
+    borrow &= ~t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void core_peel_group_kernel(const GraphDev* __restrict__ graphs,
+                                                               unsigned short* __restrict__ c,
+                                                               int* __restrict__ steps_out) {
+  __shared__ unsigned short list[2][PEEL_LIST];
+  __shared__ int leaving_s[3], alive_s[3], min_s[3];
+  const GraphDev G = graphs[blockIdx.x];
+  const int n = G.n, words = G.words, nbits = G.nbits;
+  if (n <= 0) return;  // block-uniform
+  const int w = threadIdx.x;  // this lane's word of the alive set
+  unsigned short* const cg = c + G.c_off;
+  unsigned long long pl[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) pl[p] = 0;
+  unsigned long long alive = 0;
+  if (w < words) {
+    const int left = n - 64 * w;  // >= 1: words = ceil(n / 64)
+    alive = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+    for (int b = 0; b < 64 && b < left; ++b) {
+      const unsigned long long d = cg[64 * w + b];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) pl[p] |= ((d >> p) & 1ull) << b;
+    }
+  }
+  if (threadIdx.x < 3) leaving_s[threadIdx.x] = 0, alive_s[threadIdx.x] = 0, min_s[threadIdx.x] = INT_MAX;
+  __syncthreads();
+  int k = 0, steps = 0;
+  for (int it = 0;; ++it) {
+    // the counters rotate through three slots: slot s is filled before this step's barrier, read
+    // after it, and cleared two steps later, when every thread is past the barrier in between
+    const int s = it % 3;
+    unsigned short* const mine = list[it & 1];
+    if (threadIdx.x == 0) {
+      const int z = (it + 1) % 3;
+      leaving_s[z] = 0, alive_s[z] = 0, min_s[z] = INT_MAX;
+    }
+    // alive vertices of this word with a remaining degree <= k
+    unsigned long long lt = 0, eq = alive;
+#pragma unroll
+    for (int p = 15; p >= 0; --p)
+      if (p < nbits) {
+        if ((k >> p) & 1) lt |= eq & ~pl[p], eq &= pl[p];
+        else eq &= ~pl[p];
+      }
+    unsigned long long go = lt | eq;
+    if (go) {
+      const int want = __builtin_popcountll(go);
+      const int base = atomicAdd(&leaving_s[s], want);
+      int take = min(want, max(0, PEEL_LIST - base));  // a full list: the others stay alive for now
+      int pos = base;
+      unsigned long long taken = 0;
+      for (unsigned long long m = go; m && take > 0; m &= m - 1, --take) {
+        const int b = __builtin_ctzll(m);
+        taken |= 1ull << b;
+        mine[pos++] = (unsigned short)(64 * w + b);
+        cg[64 * w + b] = (unsigned short)k;
+      }
+      alive &= ~taken;
+    }
+    if (alive) alive_s[s] = 1;
+    __syncthreads();
+    if (alive_s[s] == 0) {  // nothing is left: the vertices that have just left need no processing
+      if (leaving_s[s] > 0) ++steps;
+      break;
+    }
+    const int leaving = min(leaving_s[s], PEEL_LIST);
+    if (leaving == 0) {
+      // no vertex at this level: on to the smallest remaining degree (per lane: the smallest of its
+      // alive vertices, bit by bit from the top plane down)
+      int val = INT_MAX;
+      if (alive) {
+        unsigned long long cand = alive;
+        val = 0;
+#pragma unroll
+        for (int p = 15; p >= 0; --p) {
+          const unsigned long long t = cand & ~pl[p];
+          cand = t ? t : cand;
+          val |= t ? 0 : (1 << p);
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) val = min(val, __shfl_xor(val, off));
+      if ((threadIdx.x & 63) == 0 && val != INT_MAX) atomicMin(&min_s[s], val);
+      __syncthreads();
+      k = max(k + 1, min_s[s]);
+      continue;
+    }
+    ++steps;
+    // every alive neighbour of a leaving vertex loses one
+    for (int j0 = 0; j0 < leaving; j0 += PEEL_AHEAD) {
+      unsigned long long row[PEEL_AHEAD];
+#pragma unroll
+      for (int i = 0; i < PEEL_AHEAD; ++i)
+        row[i] = (w < words && j0 + i < leaving) ? G.bits[(size_t)mine[j0 + i] * words + w] : 0ull;
+#pragma unroll
+      for (int i = 0; i < PEEL_AHEAD; ++i) {
+        const unsigned long long m = row[i] & alive;
+        if (__ballot(m != 0)) peel_decrement(pl, m);
+      }
+    }
+  }
+  if (threadIdx.x == 0 && steps_out) steps_out[blockIdx.x] = steps;
+}
+
 // elig bit u = (core number of u) + 1 > mc, for every pair (blockIdx.y); also hands the pair's
 // set slots out afresh (tickets[p] = slots taken, best_key[p] = best (size, earliest start) so far)
 __global__ __launch_bounds__(256) void clique_eligible_group_kernel(const GraphDev* __restrict__ graphs,
@@ -629,9 +760,11 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     return hipMemcpyAsync(B.table.p, B.h_up.p, tab_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
   };
   // ---- core numbers ----------------------------------------------------------------------------
+  static const bool use_hindex = std::getenv("LGICP_CORE_HINDEX") != nullptr;
   if (hipMemsetAsync(B.c.p, 0, sizeof(unsigned short) * total_c, st) != hipSuccess ||
-      hipMemsetAsync(B.planes_a.p, 0, sizeof(unsigned long long) * total_pl, st) != hipSuccess ||
-      hipMemsetAsync(B.planes_b.p, 0, sizeof(unsigned long long) * total_pl, st) != hipSuccess || !upload_table())
+      (use_hindex && (hipMemsetAsync(B.planes_a.p, 0, sizeof(unsigned long long) * total_pl, st) != hipSuccess ||
+                      hipMemsetAsync(B.planes_b.p, 0, sizeof(unsigned long long) * total_pl, st) != hipSuccess)) ||
+      !upload_table())
     return false;
   for (int p = 0; p < P; ++p)
     hipLaunchKernelGGL(lgicp::graph_degree_kernel, dim3((tab[p].n + 3) / 4), dim3(256), 0, st, tab[p].bits,
@@ -639,6 +772,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   static std::once_flag attr_once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(attr_once, [] {
+
     const void* fns[4] = {reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<2>),
                           reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<4>),
                           reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<8>),
@@ -665,6 +799,25 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   bool first_chunk = true;
   std::vector<char> settled((size_t)P, 0);
   int n_rounds = 0, n_alive = P;
+  if (!use_hindex) {
+    (void)hipEventRecord(B.ev[0], st);
+    hipLaunchKernelGGL(lgicp::core_peel_group_kernel, dim3((unsigned)P), dim3(64 * ((max_words + 63) / 64)), 0, st,
+                       B.table.p, B.c.p, B.flags.p);
+    (void)hipEventRecord(B.ev[1], st);
+    int* h_steps = reinterpret_cast<int*>(B.h_down.p);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(h_steps, B.flags.p, sizeof(int) * (size_t)P, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return false;
+    for (int p = 0; p < P; ++p) n_rounds = std::max(n_rounds, h_steps[p]);
+    if (times) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->hindex_ms += ms;
+      ++times->hindex_launches;
+      for (int p = 0; p < P; ++p) times->hindex_matrix_bytes += (double)tab[p].n * tab[p].words * 8.0;
+    }
+    n_alive = 0;
+  }
   int2* h_blk = reinterpret_cast<int2*>(B.h_up.p + tab_bytes);
   while (n_alive > 0) {  // every round lowers at least one value of a pair or settles it
     // the workgroups of a round, by colour: 64-vertex group g of a graph has colour g mod kColours
