@@ -392,7 +392,7 @@ def main():
         acc = dict(nn_ms=0.0, nn_launches=0.0, nn_evals=0.0, nn_exec=0.0, red_ms=0.0,
                    red_launches=0.0, red_points=0.0, red_inliers=0.0, cycle_exits=0.0,
                    clique_ms=0.0, clique_bytes=0.0, clique_launches=0.0,
-                   hindex_ms=0.0, hindex_bytes=0.0, hindex_launches=0.0)
+                   core_ms=0.0, core_bytes=0.0, core_launches=0.0)
         stage = dict(nn=0.0, reduce=0.0, solve=0.0, cov=0.0, post=0.0, total=0.0)
         s_begin = ctx.stats()
         res = []
@@ -431,7 +431,7 @@ def main():
         acc = dict(nn_ms=0.0, nn_launches=0.0, nn_evals=0.0, nn_exec=0.0, red_ms=0.0,
                    red_launches=0.0, red_points=0.0, red_inliers=0.0, cycle_exits=0.0,
                    clique_ms=0.0, clique_bytes=0.0, clique_launches=0.0,
-                   hindex_ms=0.0, hindex_bytes=0.0, hindex_launches=0.0)
+                   core_ms=0.0, core_bytes=0.0, core_launches=0.0)
         stage = dict(nn=0.0, reduce=0.0, solve=0.0, cov=0.0, post=0.0, total=0.0)
         res = []
         for i in range(first, first + n_steps):
@@ -453,9 +453,9 @@ def main():
             acc["clique_ms"] += s1.clique_ms
             acc["clique_bytes"] += s1.clique_row_bytes
             acc["clique_launches"] += s1.clique_launches
-            acc["hindex_ms"] += s1.hindex_ms
-            acc["hindex_bytes"] += s1.hindex_matrix_bytes
-            acc["hindex_launches"] += s1.hindex_launches
+            acc["core_ms"] += s1.core_ms
+            acc["core_bytes"] += s1.core_matrix_bytes
+            acc["core_launches"] += s1.core_launches
             for k in stage:
                 stage[k] += getattr(s1, k + "_ms")
         return acc, stage, res
@@ -681,7 +681,7 @@ def main():
         if args.config == "C4" and args.c4_init == "teaser":
             # the kernels the C4 step spends its time in belong to the TEASER++ initialisation
             k_cl = pmc_kernel(pmc, "lgicp::clique_starts_group_kernel")
-            k_hx = pmc_kernel(pmc, "lgicp::core_hindex_group_kernel")
+            k_core = pmc_kernel(pmc, "lgicp::core_peel_group_kernel")
 
             # with two submits in flight the launch durations of one overlap the other's kernels:
             # the figures come from the phase that runs the same steps one at a time
@@ -709,12 +709,13 @@ def main():
                 "(about a tenth of the step).  The rows of a graph are read again and again by its "
                 "starts, so most of these bytes are served by L2 / Infinity Cache (see traffic); the kernel is "
                 "bound by the chain ballot -> row fetch -> intersect -> count of every step, not by HBM.")
-            out["roofline_hindex"] = hbm_line(
-                "lgicp::core_hindex_group_kernel", t_acc["hindex_ms"], t_acc["hindex_bytes"], t_acc["hindex_launches"],
-                k_hx, "core numbers by H-operator rounds. algorithmic bytes: the bit matrix (n*n/8 B) of every "
-                "graph still iterating, once per round.  Each probe of a vertex's new value re-reads its row and "
-                "compares it against the bit planes of all values in LDS, so the kernel is bound by LDS "
-                "bandwidth and issue, not by HBM.")
+            out["roofline_core_numbers"] = hbm_line(
+                "lgicp::core_peel_group_kernel", t_acc["core_ms"], t_acc["core_bytes"], t_acc["core_launches"],
+                k_core, "core numbers by peeling, one workgroup per graph, one launch per group of pairs. "
+                "algorithmic bytes: the bit matrix (n*n/8 B) of every graph once (a vertex's row is read when "
+                "it leaves).  A graph is a chain of thousands of dependent steps (compare, barrier, row fetch, "
+                "decrement), so a launch lasts as long as its longest chain at one memory latency per step: "
+                "the kernel is bound by that latency, not by HBM bandwidth.")
         if not args.no_cpu and world == 1:
             cores = cpu_threads_available()
             if args.config == "C4":

@@ -173,9 +173,9 @@ typedef struct lgicp_stats {
   double clique_ms;             /* clique_starts_group_kernel */
   double clique_row_bytes;      /* one row per start and per clique member a start tried */
   uint64_t clique_launches;
-  uint64_t hindex_launches;
-  double hindex_ms;             /* core_hindex_group_kernel */
-  double hindex_matrix_bytes;   /* the bit matrix of every graph still iterating, once per round */
+  uint64_t core_launches;
+  double core_ms;               /* core_peel_group_kernel */
+  double core_matrix_bytes;     /* the bit matrix of every graph, once */
 } lgicp_stats;
 
 typedef struct lgicp_ctx lgicp_ctx;
@@ -330,6 +330,17 @@ int lgicp_teaser_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const f
                                    size_t n_src, const float* tgt_xyz, const float* tgt_normals,
                                    size_t n_tgt, const float guess[16], float T_out[16],
                                    int32_t* used_teaser, int32_t* n_matches, int32_t* n_clique);
+
+/* The inlier selection inside TEASER++ as GetTeaserInitialAlignment configures it
+ * (IcpLoopComputation.cc:1011: inlier_selection_mode PMC_HEU): core numbers of the consistency
+ * graph, then the greedy clique heuristic over the vertices in core order.  adjacency: n rows of
+ * (n + 63) / 64 64-bit words, bit j of row i set when matches i and j are consistent (symmetric,
+ * no self loops, bits beyond n clear).  clique_out (room for n entries) receives the clique's
+ * vertices in ascending order.  At most 65536 vertices.  The step lgicp_submit and
+ * lgicp_teaser_initial_alignment run on the graphs they build themselves, exposed for graphs a
+ * caller brings. */
+int lgicp_teaser_clique(lgicp_ctx* ctx, const uint64_t* adjacency, size_t n, int32_t* clique_out,
+                        int32_t* n_clique);
 
 /* No counterpart in the reference.  lgicp_nn_search for callers that cannot allocate device
  * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc):

@@ -20,7 +20,7 @@ EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_
            "lgicp_harris_keypoints", "lgicp_sac_initial_alignment",
            "lgicp_teaser_initial_alignment", "lgicp_compute_normals", "lgicp_icp_observability",
            "lgicp_voxel_grid", "lgicp_random_sample", "lgicp_nn_search_static", "lgicp_add_keyframes", "lgicp_wait_registered",
-           "lgicp_set_submit_lanes"]
+           "lgicp_set_submit_lanes", "lgicp_teaser_clique"]
 
 
 class Config(C.Structure):
@@ -68,8 +68,8 @@ class Stats(C.Structure):
                 ("reduce_points", C.c_double), ("reduce_inliers", C.c_double),
                 ("reduce_launches", C.c_uint64), ("cycle_exits", C.c_uint64),
                 ("clique_ms", C.c_double), ("clique_row_bytes", C.c_double),
-                ("clique_launches", C.c_uint64), ("hindex_launches", C.c_uint64),
-                ("hindex_ms", C.c_double), ("hindex_matrix_bytes", C.c_double)]
+                ("clique_launches", C.c_uint64), ("core_launches", C.c_uint64),
+                ("core_ms", C.c_double), ("core_matrix_bytes", C.c_double)]
 
 
 class LgicpError(RuntimeError):
@@ -124,6 +124,8 @@ def lib():
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
             C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
             C.POINTER(C.c_int32)]
+        L.lgicp_teaser_clique.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.POINTER(C.c_int32)]
         L.lgicp_compute_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                             C.c_void_p]
         L.lgicp_icp_observability.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -339,6 +341,19 @@ class Context:
             self._h, _ptr(a[0]), _ptr(a[1]), len(a[0]), _ptr(a[2]), _ptr(a[3]), len(a[2]), _ptr(g),
             _ptr(T), C.byref(used), C.byref(nm), C.byref(nc)))
         return T.reshape(4, 4), bool(used.value), nm.value, nc.value
+
+    def teaser_clique(self, adj):
+        """adj: n x n boolean adjacency (symmetric, no self loops).  The clique as sorted indices."""
+        adj = np.asarray(adj, bool)
+        n = len(adj)
+        words = (n + 63) // 64
+        padded = np.zeros((n, words * 64), np.uint8)
+        padded[:, :n] = adj
+        bits = np.ascontiguousarray(np.packbits(padded, axis=1, bitorder="little")).view("<u8")
+        out = np.empty(max(n, 1), np.int32)
+        m = C.c_int32()
+        self._check(lib().lgicp_teaser_clique(self._h, _ptr(bits), n, _ptr(out), C.byref(m)))
+        return out[:m.value].copy()
 
     def compute_normals(self, xyz, k=10):
         x = _f32(xyz).reshape(-1, 3)

@@ -109,12 +109,22 @@ __global__ void feature_knn_merge_kernel(int n_src, int n_splits, int k,
   int bi[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) bd[s] = __builtin_inff(), bi[s] = -1;
+  // a range's list arrives whole (two 16-byte loads each for distances and indices, independent
+  // from range to range); its unused entries are +inf and never pass the strict `<`
+#pragma unroll 4
   for (int r = 0; r < n_splits; ++r) {
     const size_t o = ((size_t)r * n_src + i) * 8;
-    for (int e = 0; e < k; ++e) {
-      float cd = part_d[o + e];
-      int ci = part_i[o + e];
-      if (ci < 0) break;
+    const float4 d0 = *reinterpret_cast<const float4*>(part_d + o);
+    const float4 d1 = *reinterpret_cast<const float4*>(part_d + o + 4);
+    const int4 i0 = *reinterpret_cast<const int4*>(part_i + o);
+    const int4 i1 = *reinterpret_cast<const int4*>(part_i + o + 4);
+    const float ld[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const int li[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e >= k) break;
+      float cd = li[e] < 0 ? __builtin_inff() : ld[e];
+      int ci = li[e];
 #pragma unroll
       for (int s = 0; s < 8; ++s)
         if (s < k) {

@@ -831,8 +831,8 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
       if (helper.joinable()) helper.join();
       stats.clique_ms += ct.starts_ms, stats.clique_row_bytes += ct.starts_row_bytes;
       stats.clique_launches += ct.starts_launches;
-      stats.hindex_ms += ct.hindex_ms, stats.hindex_matrix_bytes += ct.hindex_matrix_bytes;
-      stats.hindex_launches += ct.hindex_launches;
+      stats.core_ms += ct.core_ms, stats.core_matrix_bytes += ct.core_matrix_bytes;
+      stats.core_launches += ct.core_launches;
       if (rc != LGICP_OK) return rc;
       for (int j = 0; j < g; ++j) {
         const int p = cur->pair[j];
@@ -1500,8 +1500,8 @@ void merge_stats(lgicp_stats& into, const lgicp_stats& d) {
   into.cycle_exits += d.cycle_exits;
   into.clique_ms += d.clique_ms, into.clique_row_bytes += d.clique_row_bytes;
   into.clique_launches += d.clique_launches;
-  into.hindex_ms += d.hindex_ms, into.hindex_matrix_bytes += d.hindex_matrix_bytes;
-  into.hindex_launches += d.hindex_launches;
+  into.core_ms += d.core_ms, into.core_matrix_bytes += d.core_matrix_bytes;
+  into.core_launches += d.core_launches;
   if (d.last_nn_evals_per_launch > 0) {
     into.last_nn_kernel_ms = d.last_nn_kernel_ms;
     into.last_nn_evals_per_launch = d.last_nn_evals_per_launch;
@@ -1513,8 +1513,8 @@ void reset_submit_stats(lgicp_stats& s) {
   s.nn_executed_evals = s.reduce_points = s.reduce_inliers = 0;
   s.reduce_launches = 0;
   s.cycle_exits = 0;
-  s.clique_ms = s.clique_row_bytes = s.hindex_ms = s.hindex_matrix_bytes = 0;
-  s.clique_launches = s.hindex_launches = 0;
+  s.clique_ms = s.clique_row_bytes = s.core_ms = s.core_matrix_bytes = 0;
+  s.clique_launches = s.core_launches = 0;
 }
 
 }  // namespace

@@ -401,8 +401,8 @@ struct CliqueGraph {
   int n, words;
 };
 struct CliqueTimes {  // hipEvent durations and algorithmic bytes of the two kernels, accumulated
-  double starts_ms = 0, starts_row_bytes = 0, hindex_ms = 0, hindex_matrix_bytes = 0;
-  uint64_t starts_launches = 0, hindex_launches = 0;
+  double starts_ms = 0, starts_row_bytes = 0, core_ms = 0, core_matrix_bytes = 0;
+  uint64_t starts_launches = 0, core_launches = 0;
 };
 // rerun_improving: ignore the member sets the windows kept and run every improving start once
 // more on its own (the fallback for a start that found no free slot; a switch for tests)

@@ -383,6 +383,29 @@ int lgicp_teaser_initial_alignment(lgicp_ctx* ctx, const float* src_xyz, const f
   return rc;
 }
 
+int lgicp_teaser_clique(lgicp_ctx* ctx, const uint64_t* adjacency, size_t n, int32_t* clique_out,
+                        int32_t* n_clique) {
+  if (!ctx || !adjacency || !clique_out || !n_clique) return fail(ctx, LGICP_E_INVALID, "null argument");
+  *n_clique = 0;
+  if (n == 0) return LGICP_OK;
+  if (n > (size_t)clique_device_max_vertices())
+    return fail(ctx, LGICP_E_UNSUPPORTED, "graph of %zu vertices: the device search takes at most %d", n,
+                clique_device_max_vertices());
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  const size_t words = (n + 63) / 64;
+  unsigned long long* d_bits = nullptr;
+  if (hipMalloc((void**)&d_bits, sizeof(uint64_t) * n * words) != hipSuccess)
+    return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  std::vector<int> clique;
+  bool ok = hipMemcpy(d_bits, adjacency, sizeof(uint64_t) * n * words, hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && greedy_clique_device(ctx->cfg.device, ctx->stream, d_bits, (int)n, (int)words, &clique);
+  (void)hipFree(d_bits);
+  if (!ok) return fail(ctx, LGICP_E_HIP, "clique search on the device failed (%s)", hipGetErrorString(hipGetLastError()));
+  for (size_t i = 0; i < clique.size(); ++i) clique_out[i] = clique[i];
+  *n_clique = (int32_t)clique.size();
+  return LGICP_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------

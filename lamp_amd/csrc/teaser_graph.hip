@@ -5,18 +5,13 @@
 // consistency_graph_kernel left in device memory (they never travel to the host), for a whole
 // group of candidate pairs at a time.
 //
-// Both halves are chains of small dependent steps (one launch per H-operator round, one per window
-// of clique starts, each lasting as long as its slowest wave), so one pair alone leaves the GPU
-// idle; every launch here therefore carries the step of all pairs of the group, and a step costs
-// the slowest pair's latency once per group.
+// Both halves are chains of small dependent steps (a peeling step, a window of clique starts, each
+// lasting as long as its slowest wave), so one pair alone leaves the GPU idle; every launch here
+// therefore carries all pairs of the group.
 //
-// Core numbers: the H-operator iteration (Lu, Zhou, Zhang, Stanley 2016: starting from the degrees,
-// c(v) <- H-index of the neighbours' values converges to the core numbers).  Every round is one
-// fully parallel launch (one wave per four vertices, the previous round's values in LDS) and a few
-// tens of rounds suffice on these graphs, where level-by-level peeling pays a grid-wide step for
-// each of the thousands of distinct core values and bucket peeling is sequential.  Core numbers are
-// a property of the graph, so the result equals the host's bucket peeling (teaser::core_bounds)
-// entry by entry.
+// Core numbers: peeling, one workgroup per graph with the remaining degrees in registers as bit
+// planes (core_peel_group_kernel).  Core numbers are a property of the graph, so the result equals
+// the host's bucket peeling (teaser::core_bounds) entry by entry.
 //
 // clique_starts_group_kernel: one wave per start of the greedy heuristic (teaser::greedy_clique's
 // start_from): candidates = neighbours of the start vertex whose bound exceeds the best size so
@@ -53,13 +48,9 @@ struct GraphDev {
   int list_off;  // first word of the member-set slots this round's starts may fill
   int n_pad;     // elements of the per-vertex arrays (n rounded up to a multiple of 8, plus 8)
   int nbits;     // bits of a per-vertex value (values < n <= 2^nbits)
-  int stride;    // words per bit plane (words rounded up to even)
-  int pl_off;    // first word of the pair's bit planes
+  int stride;    // words of a member-set slot (words rounded up to even)
 };
 
-constexpr int HX_ROUNDS = 8;        // H-operator rounds between two looks at the flags
-constexpr int HX_VPW = 16;          // vertices per wave and round
-constexpr int HX_VPB = 4 * HX_VPW;  // per workgroup of four waves: the 64 vertices of one bit-set word
 constexpr int CLQ_MAX_WORDS = 1024;  // 65536 matches
 constexpr int CLQ_SLOTS = 16;        // member sets a pair can keep per round (+1 for a start run alone)
 
@@ -87,231 +78,6 @@ __global__ __launch_bounds__(256) void graph_degree_kernel(const unsigned long l
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
   if (lane == 0) deg[v] = (unsigned short)d;  // d < n <= 65536
-}
-
-// Bit planes of the per-vertex values of every pair: bit v of plane b = bit b of value(v).
-// blk[g] = (pair, first vertex) of one 64-vertex group; one wave per group.
-__global__ __launch_bounds__(256) void value_planes_kernel(const GraphDev* __restrict__ graphs,
-                                                           const int2* __restrict__ blk, int n_groups,
-                                                           const unsigned short* __restrict__ c,
-                                                           unsigned long long* __restrict__ planes) {
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (g >= n_groups) return;  // wave-uniform
-  const int2 b = blk[g];
-  const GraphDev G = graphs[b.x];
-  const int v = b.y + lane;
-  const int val = v < G.n ? (int)c[G.c_off + v] : 0;
-  for (int q = 0; q < G.nbits; ++q) {
-    const unsigned long long m = __ballot((val >> q) & 1);
-    if (lane == 0) planes[(size_t)G.pl_off + (size_t)q * G.stride + (b.y >> 6)] = m;
-  }
-}
-
-// One round of the H-operator for every pair of the group: c_new(v) = the largest h such that at
-// least h neighbours u of v have c_old(u) >= h (never more than c_old(v)).  The values of a round
-// come from the round before alone, so the rounds are deterministic.  blk[b] = (pair, first vertex)
-// of workgroup b, which owns the 64 vertices of one word; flags[pair][r] is raised when a value of
-// the pair moved in round r, and a pair whose previous round moved nothing is skipped (both plane
-// arrays hold its fixed point by then).
-// The old values live in LDS as bit planes, and "neighbours with a value >= h" is counted bit-set
-// wise: per word of the row, the bit-sliced comparison of 64 values with h (a few operations per
-// plane), an AND and a population count - a cost per vertex that depends on the size of the graph
-// and not on its density, against one LDS gather per neighbour when the values are kept as numbers
-// (these graphs have thousands of neighbours per vertex).  The probes of one vertex mostly differ in
-// their low bits only, so the state of the comparison after the planes above HX_LOW is kept per word
-// and reused while the probes stay within the same block of 2^HX_LOW values; the vertex's row sits
-// in registers for all its probes.  WPL = 64-bit words of a row per lane.
-// dynamic LDS: nbits planes of `stride` words.
-constexpr int HX_LOW = 6;
-template <int WPL>
-__global__ __launch_bounds__(256) void core_hindex_group_kernel(const GraphDev* __restrict__ graphs,
-                                                                const int2* __restrict__ blk,
-                                                                const unsigned long long* __restrict__ planes_old,
-                                                                unsigned long long* __restrict__ planes_new,
-                                                                unsigned short* __restrict__ c_out,
-                                                                int* __restrict__ flags, int r, int mode) {
-  extern __shared__ __align__(16) unsigned long long pl[];
-  __shared__ unsigned short res[HX_VPB];
-  const int2 b = blk[blockIdx.x];
-  const int p = b.x;
-  // a pair whose previous round (all its colours) moved nothing is at rest
-  if (r > 0 && flags[p * HX_ROUNDS + r - 1] == 0) return;  // uniform over the workgroup
-  const GraphDev G = graphs[p];
-  const int n = G.n, words = G.words, nbits = G.nbits, stride = G.stride;
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(planes_old + G.pl_off);
-    uint4* dst = reinterpret_cast<uint4*>(pl);
-    const int nv = (nbits * stride) >> 1;  // stride is even
-    for (int i = threadIdx.x; i < nv; i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // The wave's vertices in the order of their values: lane l < HX_VPW reads the value of vertex l
-  // from the planes and ranks it.  The comparison state after the high planes depends on the
-  // threshold's high bits alone, not on the vertex, so it carries over from one vertex to the next
-  // when they share those bits - in a dense graph most values lie close together.
-  int my_val = -1;
-  {
-    const int v = b.y + wave * HX_VPW + lane;
-    if (lane < HX_VPW && v < n) {
-      my_val = 0;
-      for (int k = 0; k < nbits; ++k) my_val |= (int)((pl[k * stride + (v >> 6)] >> (v & 63)) & 1ull) << k;
-    }
-  }
-  int my_rank = 0;
-  for (int j = 0; j < HX_VPW; ++j) {
-    const int vj = __builtin_amdgcn_readlane(my_val, j);
-    my_rank += (vj > my_val || (vj == my_val && j < lane)) ? 1 : 0;
-  }
-  unsigned long long sgt[WPL], seq[WPL];
-  int saved = -1;  // sgt / seq hold the comparison state of thresholds h with h >> HX_LOW == saved
-  for (int turn = 0; turn < HX_VPW; ++turn) {
-    const int q = __builtin_ctzll(__ballot(lane < HX_VPW && my_rank == turn) | (1ull << 63));  // wave-uniform
-    const int v = b.y + wave * HX_VPW + q;
-    const int cv = __builtin_amdgcn_readlane(my_val, q);
-    if (cv < 0) {  // no such vertex
-      if (lane == 0) res[wave * HX_VPW + q] = 0;
-      continue;
-    }
-    unsigned long long row[WPL];
-    {
-      const unsigned long long* rp = G.bits + (size_t)v * words;
-#pragma unroll
-      for (int k = 0; k < WPL; ++k) {
-        const int w = lane + 64 * k;
-        row[k] = w < words ? rp[w] : 0ull;
-      }
-    }
-    auto count_ge = [&](int h) {  // neighbours whose value is at least h
-      const int prefix = h >> HX_LOW;
-      const bool reuse = prefix == saved;  // wave-uniform
-      int c = 0;
-#pragma unroll
-      for (int k = 0; k < WPL; ++k) {
-        const int w = lane + 64 * k;
-        if (w >= words) continue;
-        unsigned long long gt, eq;
-        if (reuse) {
-          gt = sgt[k], eq = seq[k];
-        } else {
-          gt = 0, eq = ~0ull;
-          for (int b2 = nbits - 1; b2 >= HX_LOW; --b2) {
-            const unsigned long long P = pl[b2 * stride + w];
-            if ((h >> b2) & 1) {  // wave-uniform
-              eq &= P;
-            } else {
-              gt |= eq & P;
-              eq &= ~P;
-            }
-          }
-          sgt[k] = gt, seq[k] = eq;
-        }
-        for (int b2 = min(nbits, HX_LOW) - 1; b2 >= 0; --b2) {
-          const unsigned long long P = pl[b2 * stride + w];
-          if ((h >> b2) & 1) {
-            eq &= P;
-          } else {
-            gt |= eq & P;
-            eq &= ~P;
-          }
-        }
-        c += __builtin_popcountll(row[k] & (gt | eq));
-      }
-      saved = prefix;
-      return wave_sum(c);
-    };
-    // H lies in [lo, hi].  A probe p with count c = count_ge(p) narrows both ends: count_ge never
-    // grows with h, so c >= p means p <= H <= c, and c < p means c <= H <= p - 1 (count_ge(c) >=
-    // count_ge(p) = c).  The new value usually lies just below the old one (the counts jump where
-    // many neighbours share a value), so the probes gallop down from the top, then bisect.
-    int h = cv;
-    if (mode == 2) {
-      // Coarse round: thresholds are multiples of 2^HX_LOW, for which the low planes do not matter.
-      // k* = the largest k with at least k 2^HX_LOW neighbours at or above k 2^HX_LOW brackets the
-      // H-index within 2^HX_LOW, and min(value, top of that bracket) is still an upper bound of
-      // it - all the iteration needs to stay above the core numbers.  The first rounds, in which
-      // the values fall by thousands from the degrees, get there with a third of the work; the
-      // exact rounds that follow finish the job (and define the result).
-      auto count_coarse = [&](int k) {
-        const int hh = k << HX_LOW;
-        int c = 0;
-#pragma unroll
-        for (int q2 = 0; q2 < WPL; ++q2) {
-          const int w = lane + 64 * q2;
-          if (w >= words) continue;
-          unsigned long long gt = 0, eq = ~0ull;
-          for (int b2 = nbits - 1; b2 >= HX_LOW; --b2) {
-            const unsigned long long P = pl[b2 * stride + w];
-            if ((hh >> b2) & 1) {
-              eq &= P;
-            } else {
-              gt |= eq & P;
-              eq &= ~P;
-            }
-          }
-          c += __builtin_popcountll(row[q2] & (gt | eq));
-        }
-        return wave_sum(c);
-      };
-      const int kv = cv >> HX_LOW;
-      if (kv > 0) {
-        const int c0 = count_coarse(kv);
-        if (c0 < (kv << HX_LOW)) {
-          int lo = c0 >> HX_LOW, hi = kv - 1;
-          while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            const int c = count_coarse(mid);
-            if (c >= (mid << HX_LOW)) {
-              lo = mid;
-              hi = min(hi, c >> HX_LOW);
-            } else {
-              hi = mid - 1;
-              lo = max(lo, c >> HX_LOW);
-            }
-          }
-          h = min(cv, (lo << HX_LOW) + (1 << HX_LOW) - 1);
-        }
-      }
-    } else if (cv > 0) {
-      const int c0 = count_ge(cv);
-      if (c0 < cv) {
-        int lo = c0, hi = cv - 1, step = 1;
-        auto probe_at = [&](int probe) {
-          const int c = count_ge(probe);
-          if (c >= probe) {
-            lo = probe;
-            hi = min(hi, c);
-            return true;
-          }
-          hi = probe - 1;
-          lo = max(lo, c);
-          return false;
-        };
-        // (in the first rounds the values fall by hundreds or thousands - they start from the
-        // degrees - and the gallop would spend a dozen probes to get there: bisect at once)
-        while (mode == 0 && lo < hi) {
-          const int probe = hi - step + 1;
-          if (probe <= lo || probe_at(probe)) break;
-          step <<= 1;
-        }
-        while (lo < hi) probe_at((lo + hi + 1) >> 1);
-        h = lo;
-      }
-    }
-    if (lane == 0) {
-      res[wave * HX_VPW + q] = (unsigned short)h;
-      c_out[G.c_off + v] = (unsigned short)h;
-      if (h != cv) flags[p * HX_ROUNDS + r] = 1;
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {  // the planes of the 64 new values
-    const int val = (int)res[lane];
-    for (int k = 0; k < nbits; ++k) {
-      const unsigned long long m = __ballot((val >> k) & 1);
-      if (lane == 0) planes_new[(size_t)G.pl_off + (size_t)k * stride + (b.y >> 6)] = m;
-    }
-  }
 }
 
 // Core numbers by peeling, one workgroup per graph, one lane per 64-bit word of the alive set.
@@ -649,10 +415,10 @@ struct PinBuf {  // grow-only pinned host array
 struct CliqueGroupDev {
   int device = -1;
   DevBuf<unsigned short> c, pref;
-  DevBuf<unsigned long long> elig, planes_a, planes_b, sets;
+  DevBuf<unsigned long long> elig, sets;
   DevBuf<lgicp::GraphDev> table;
-  DevBuf<int2> blk, starts;
-  DevBuf<int> flags, out, tickets;
+  DevBuf<int2> starts;
+  DevBuf<int> steps, out, tickets;
   DevBuf<unsigned long long> rows_read, best_key;
   hipEvent_t ev[2] = {nullptr, nullptr};
   PinBuf h_up, h_down;
@@ -662,8 +428,7 @@ struct CliqueGroupDev {
       (void)hipGetDevice(&cur);
       if (cur != device) (void)hipSetDevice(device);
       c.release(), pref.release(), sets.release(), elig.release(), table.release();
-      planes_a.release(), planes_b.release();
-      blk.release(), starts.release(), flags.release(), out.release(), tickets.release();
+      starts.release(), steps.release(), out.release(), tickets.release();
       h_up.release(), h_down.release(), rows_read.release(), best_key.release();
       for (hipEvent_t& e : ev) {
         if (e) (void)hipEventDestroy(e);
@@ -676,12 +441,11 @@ struct CliqueGroupDev {
   ~CliqueGroupDev() { release(); }
 };
 constexpr int kMaxWindow = 65536;
-constexpr int kColours = 2;  // colours of an H-operator round
-constexpr int kCoarseRounds = 16;  // H-operator rounds at the start that work on multiples of 64 (one or more chunks of HX_ROUNDS)
 }  // namespace
 
-// largest graph the device path takes: the H-operator kernel keeps one unsigned short per vertex
-// in LDS (128 KiB at 65536 vertices, the size the consistency graph is capped at anyway)
+// largest graph the device path takes: vertex ids and core numbers travel as unsigned short, and the
+// peeling kernel gives a row's 64-bit words one lane each of a workgroup of at most 1024 (65536
+// vertices, the size the consistency graph is capped at anyway)
 int clique_device_max_vertices() { return 65536; }
 
 // teaser::greedy_clique on `count` bit matrices in device memory, all of them advancing together.
@@ -720,7 +484,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   // ---- layout ----------------------------------------------------------------------------------
   std::vector<GraphDev> tab((size_t)P);
   std::vector<size_t> list_base((size_t)P);
-  size_t total_c = 0, total_w = 0, total_l = 0, total_blk = 0, total_pl = 0;
+  size_t total_c = 0, total_w = 0, total_l = 0;
   int max_n = 0, max_words = 0;
   for (int p = 0; p < P; ++p) {
     const CliqueGraph& g = gr[ids[p]];
@@ -733,160 +497,52 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     t.nbits = 1;
     while ((1 << t.nbits) < g.n) ++t.nbits;  // values are at most n - 1
     t.stride = (g.words + 1) & ~1;
-    t.pl_off = (int)total_pl;
-    total_pl += (size_t)t.nbits * t.stride;
     list_base[p] = total_l;
     total_l += (size_t)2 * (lgicp::CLQ_SLOTS + 1) * t.stride;
     total_c += (size_t)t.n_pad;
     total_w += (size_t)g.words;
-    total_blk += (size_t)(g.n + lgicp::HX_VPB - 1) / lgicp::HX_VPB;
     max_n = std::max(max_n, g.n), max_words = std::max(max_words, g.words);
   }
-  if (total_l > (size_t)INT_MAX || total_c > (size_t)INT_MAX || total_pl > (size_t)INT_MAX) return false;
-  if (B.c.reserve(total_c) != hipSuccess || B.planes_a.reserve(total_pl) != hipSuccess ||
-      B.planes_b.reserve(total_pl) != hipSuccess ||
+  if (total_l > (size_t)INT_MAX || total_c > (size_t)INT_MAX) return false;
+  if (B.c.reserve(total_c) != hipSuccess ||
       B.pref.reserve(total_c) != hipSuccess || B.sets.reserve(total_l) != hipSuccess ||
       B.elig.reserve(total_w) != hipSuccess || B.table.reserve((size_t)P) != hipSuccess ||
-      B.blk.reserve(total_blk) != hipSuccess || B.flags.reserve((size_t)P * lgicp::HX_ROUNDS) != hipSuccess ||
+      B.steps.reserve((size_t)P) != hipSuccess ||
       B.tickets.reserve((size_t)P) != hipSuccess || B.best_key.reserve((size_t)P) != hipSuccess)
     return false;
   const size_t tab_bytes = sizeof(GraphDev) * (size_t)P;
-  const size_t up_fixed = tab_bytes + sizeof(int2) * total_blk;
-  if (!B.h_up.reserve(std::max(up_fixed, tab_bytes + sizeof(unsigned short) * total_c)) ||
-      !B.h_down.reserve(std::max(sizeof(unsigned short) * total_c, sizeof(int) * (size_t)P * lgicp::HX_ROUNDS)))
+  if (!B.h_up.reserve(tab_bytes + sizeof(unsigned short) * total_c) ||
+      !B.h_down.reserve(std::max(sizeof(unsigned short) * total_c, sizeof(int) * (size_t)P)))
     return false;
   auto upload_table = [&]() {
     std::memcpy(B.h_up.p, tab.data(), tab_bytes);
     return hipMemcpyAsync(B.table.p, B.h_up.p, tab_bytes, hipMemcpyHostToDevice, st) == hipSuccess;
   };
   // ---- core numbers ----------------------------------------------------------------------------
-  static const bool use_hindex = std::getenv("LGICP_CORE_HINDEX") != nullptr;
-  if (hipMemsetAsync(B.c.p, 0, sizeof(unsigned short) * total_c, st) != hipSuccess ||
-      (use_hindex && (hipMemsetAsync(B.planes_a.p, 0, sizeof(unsigned long long) * total_pl, st) != hipSuccess ||
-                      hipMemsetAsync(B.planes_b.p, 0, sizeof(unsigned long long) * total_pl, st) != hipSuccess)) ||
-      !upload_table())
-    return false;
+  if (hipMemsetAsync(B.c.p, 0, sizeof(unsigned short) * total_c, st) != hipSuccess || !upload_table()) return false;
   for (int p = 0; p < P; ++p)
     hipLaunchKernelGGL(lgicp::graph_degree_kernel, dim3((tab[p].n + 3) / 4), dim3(256), 0, st, tab[p].bits,
                        tab[p].n, tab[p].words, B.c.p + tab[p].c_off);
-  static std::once_flag attr_once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(attr_once, [] {
-
-    const void* fns[4] = {reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<2>),
-                          reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<4>),
-                          reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<8>),
-                          reinterpret_cast<const void*>(lgicp::core_hindex_group_kernel<16>)};
-    for (const void* f : fns) {
-      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 64);
-      if (e != hipSuccess) attr_rc = e;
-    }
-  });
-  if (attr_rc != hipSuccess) return false;
-  // The kernel keeps a vertex's row in registers, so it is instantiated per row width; the graphs of
-  // a group are launched by width class, each class with the instantiation and the LDS size it
-  // needs (one graph of more than 32,768 vertices would otherwise put every graph of its group on
-  // the widest instantiation: a quarter of the occupancy, arrays in scratch memory).
-  constexpr int kClasses = 4;
-  auto class_of = [](int words) { return words <= 128 ? 0 : words <= 256 ? 1 : words <= 512 ? 2 : 3; };
-  size_t class_lds[kClasses] = {0, 0, 0, 0};
-  for (int p = 0; p < P; ++p) {
-    size_t& b = class_lds[class_of(tab[p].words)];
-    b = std::max(b, sizeof(unsigned long long) * (size_t)tab[p].nbits * tab[p].stride);
-  }
-  unsigned long long* pl_cur = B.planes_a.p;
-  unsigned long long* pl_nxt = B.planes_b.p;
-  bool first_chunk = true;
-  std::vector<char> settled((size_t)P, 0);
-  int n_rounds = 0, n_alive = P;
-  if (!use_hindex) {
+  int n_steps = 0;  // peeling steps of the graph that took the most
+  {
+    // one workgroup per graph, as many waves as the widest graph has 64-word pieces of a row
     (void)hipEventRecord(B.ev[0], st);
     hipLaunchKernelGGL(lgicp::core_peel_group_kernel, dim3((unsigned)P), dim3(64 * ((max_words + 63) / 64)), 0, st,
-                       B.table.p, B.c.p, B.flags.p);
+                       B.table.p, B.c.p, B.steps.p);
     (void)hipEventRecord(B.ev[1], st);
     int* h_steps = reinterpret_cast<int*>(B.h_down.p);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(h_steps, B.flags.p, sizeof(int) * (size_t)P, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(h_steps, B.steps.p, sizeof(int) * (size_t)P, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
       return false;
-    for (int p = 0; p < P; ++p) n_rounds = std::max(n_rounds, h_steps[p]);
+    for (int p = 0; p < P; ++p) n_steps = std::max(n_steps, h_steps[p]);
     if (times) {
       float ms = 0;
-      if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->hindex_ms += ms;
-      ++times->hindex_launches;
-      for (int p = 0; p < P; ++p) times->hindex_matrix_bytes += (double)tab[p].n * tab[p].words * 8.0;
+      if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->core_ms += ms;
+      ++times->core_launches;
+      // every vertex leaves once, and its row is read then
+      for (int p = 0; p < P; ++p) times->core_matrix_bytes += (double)tab[p].n * tab[p].words * 8.0;
     }
-    n_alive = 0;
-  }
-  int2* h_blk = reinterpret_cast<int2*>(B.h_up.p + tab_bytes);
-  while (n_alive > 0) {  // every round lowers at least one value of a pair or settles it
-    // the workgroups of a round, by colour: 64-vertex group g of a graph has colour g mod kColours
-    size_t nb = 0, part_first[kColours * kClasses + 1];  // parts: colour-major, then width class
-    for (int col = 0; col < kColours; ++col)
-      for (int cls = 0; cls < kClasses; ++cls) {
-        part_first[col * kClasses + cls] = nb;
-        for (int p = 0; p < P; ++p)
-          if (!settled[p] && class_of(tab[p].words) == cls)
-            for (int v0 = col * lgicp::HX_VPB; v0 < tab[p].n; v0 += kColours * lgicp::HX_VPB)
-              h_blk[nb++] = make_int2(p, v0);
-      }
-    part_first[kColours * kClasses] = nb;
-    if (hipMemcpyAsync(B.blk.p, h_blk, sizeof(int2) * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemsetAsync(B.flags.p, 0, sizeof(int) * (size_t)P * lgicp::HX_ROUNDS, st) != hipSuccess)
-      return false;
-    if (first_chunk) {  // the degrees as planes
-      hipLaunchKernelGGL(lgicp::value_planes_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, st, B.table.p,
-                         B.blk.p, (int)nb, B.c.p, pl_cur);
-      first_chunk = false;
-    }
-    (void)hipEventRecord(B.ev[0], st);
-    // A round goes colour by colour: the groups of one colour are recomputed from the values of
-    // all groups as they stand (the other colours' planes are carried over by a copy), so what one
-    // colour lowers the next already sees - the values then travel several steps per round, and
-    // the rounds are fewer (any order of updates that stays above the core numbers ends at them).
-    for (int r = 0; r < lgicp::HX_ROUNDS; ++r)
-      for (int col = 0; col < kColours; ++col) {
-        if (part_first[(col + 1) * kClasses] == part_first[col * kClasses]) continue;
-        if (hipMemcpyAsync(pl_nxt, pl_cur, sizeof(unsigned long long) * total_pl, hipMemcpyDeviceToDevice, st) !=
-            hipSuccess)
-          return false;
-        for (int cls = 0; cls < kClasses; ++cls) {
-          const size_t first = part_first[col * kClasses + cls];
-          const unsigned nbc = (unsigned)(part_first[col * kClasses + cls + 1] - first);
-          if (nbc == 0) continue;
-#define LGICP_HX_LAUNCH(W)                                                                                        \
-  hipLaunchKernelGGL((lgicp::core_hindex_group_kernel<W>), dim3(nbc), dim3(256), class_lds[cls], st, B.table.p,   \
-                     B.blk.p + first, pl_cur, pl_nxt, B.c.p, B.flags.p, r, n_rounds < kCoarseRounds ? 2 : 0)
-          if (cls == 0) LGICP_HX_LAUNCH(2); else if (cls == 1) LGICP_HX_LAUNCH(4);
-          else if (cls == 2) LGICP_HX_LAUNCH(8); else LGICP_HX_LAUNCH(16);
-#undef LGICP_HX_LAUNCH
-          if (times) ++times->hindex_launches;
-        }
-        std::swap(pl_cur, pl_nxt);
-      }
-    (void)hipEventRecord(B.ev[1], st);
-    n_rounds += lgicp::HX_ROUNDS;
-    int* h_flags = reinterpret_cast<int*>(B.h_down.p);
-    if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(h_flags, B.flags.p, sizeof(int) * (size_t)P * lgicp::HX_ROUNDS, hipMemcpyDeviceToHost, st) !=
-            hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      return false;
-    if (times) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, B.ev[0], B.ev[1]) == hipSuccess) times->hindex_ms += ms;
-      // a round reads the bit matrix of every pair it does not skip
-      for (int p = 0; p < P; ++p) {
-        if (settled[p]) continue;
-        int ran = 1;
-        while (ran < lgicp::HX_ROUNDS && h_flags[p * lgicp::HX_ROUNDS + ran - 1] != 0) ++ran;
-        times->hindex_matrix_bytes += (double)ran * tab[p].n * tab[p].words * 8.0;
-      }
-    }
-    // (a chunk of coarse rounds settles nothing: its fixed point is not the exact one)
-    for (int p = 0; p < P && n_rounds > kCoarseRounds; ++p)
-      if (!settled[p] && h_flags[p * lgicp::HX_ROUNDS + lgicp::HX_ROUNDS - 1] == 0) settled[p] = 1, --n_alive;
-    if (n_rounds > 4 * max_n + 64) return false;
   }
   unsigned short* h_c = reinterpret_cast<unsigned short*>(B.h_down.p);
   if (hipMemcpyAsync(h_c, B.c.p, sizeof(unsigned short) * total_c, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1079,8 +735,8 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   }
   if (trace)
     std::fprintf(stderr, "[lgicp] clique search on the device: %d graphs (largest %d vertices), core numbers %.2f ms "
-                 "(%d rounds), orders %.2f ms, %d windows / %lld starts (%lld run alone) %.2f ms\n", P, max_n, ms_core,
-                 n_rounds, ms_sort, n_windows, n_starts, n_alone, ms_since(t_2));
+                 "(%d steps), orders %.2f ms, %d windows / %lld starts (%lld run alone) %.2f ms\n", P, max_n, ms_core,
+                 n_steps, ms_sort, n_windows, n_starts, n_alone, ms_since(t_2));
   return true;
 }
 
