@@ -768,8 +768,8 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     // for one pair as for sixty-four).  Largest pairs first, so that the pairs of a group are of
     // similar size and the buffers of the slots are sized once.
     const bool trace = std::getenv("LGICP_TRACE") != nullptr;  // diagnostics on stderr
-    constexpr int kGroup = 128;
-    constexpr size_t kGroupBytes = 6ull << 30;  // bit matrices of a group
+    constexpr int kGroup = 256;
+    constexpr size_t kGroupBytes = 12ull << 30;  // bit matrices of a group
     // Two sets of slots: while the clique search of one group runs on the context's stream (chains
     // of launches that leave much of the GPU idle in their tails), a helper thread enqueues the
     // matches and graphs of the next group on a second stream.
@@ -851,7 +851,7 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     // the slots keep their bit matrices for the next submit unless they have grown large
     size_t held = 0;
     for (auto& sl : slots) held += sl->d_bits.cap * sizeof(unsigned long long);
-    if (held > (8ull << 30))
+    if (held > (32ull << 30))
       for (auto& sl : slots) sl->d_bits.release();
   }
   if (cfg.init_method == LGICP_INIT_FEATURES && n_pairs > 0) {
