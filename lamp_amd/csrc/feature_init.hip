@@ -416,7 +416,7 @@ void parallel_for(int n, F f) {
 // and keypoints the clouds' features keep there.  Everything is enqueued on the context's stream
 // and the call returns; the matched keypoints land in the job's pinned buffer.
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                          TeaserJob* job, hipStream_t st, int fset) {
+                          TeaserJob* job, hipStream_t st, int fset, int sub) {
   namespace tz = lgicp::teaser;
   job->n_matches = 0;
   job->src.clear();
@@ -441,7 +441,10 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
   }
   if (!src.d_feat || !tgt.d_feat) return fail(ctx, LGICP_E_INVALID, "cloud features without device copies");
   if (!st) st = ctx->stream;
-  MatcherDev& md = matcher_of(ctx, fset);
+  // pairs prepared side by side on several streams each need a k-NN table of their own: stream 0 of
+  // a feature set uses the set's matcher, the others the (otherwise idle) matchers of its SAC-IA lanes
+  const bool own = sub > 0 && sub < FEATURE_LANES && fset >= 0 && fset < lgicp_ctx::FEATURE_SETS;
+  MatcherDev& md = own ? ctx->sac_lanes.get()[fset * FEATURE_LANES + sub].md : matcher_of(ctx, fset);
   const tz::Params prm;
   tz::BitGraph& g = job->graph;
   g.n = n;

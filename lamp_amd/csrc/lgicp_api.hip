@@ -775,7 +775,12 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     // matches and graphs of the next group on a second stream.
     std::vector<std::shared_ptr<TeaserJob>>& slots = ctx->teaser_slots[fset];
     while ((int)slots.size() < 2 * kGroup) slots.push_back(std::make_shared<TeaserJob>());
-    hipStream_t prep_stream = ctx->n_slots >= lane0 + 2 ? ctx->slot[lane0 + 1].stream : main_stream;
+    // streams the matches and graphs of a group are enqueued on, pair after pair in turn (a pair's
+    // kernels are small: a few of them side by side fill the GPU better): the set's streams other
+    // than the one the clique search runs on
+    hipStream_t prep_streams[FEATURE_LANES - 1] = {main_stream, main_stream, main_stream};
+    const int n_prep = std::max(1, std::min(FEATURE_LANES - 1, ctx->n_slots - lane0 - 1));
+    for (int j = 0; j < n_prep && ctx->n_slots >= lane0 + 2; ++j) prep_streams[j] = ctx->slot[lane0 + 1 + j].stream;
     std::vector<int> by_size((size_t)n_pairs);
     for (int p = 0; p < n_pairs; ++p) by_size[p] = p;
     std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) {
@@ -801,17 +806,22 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
         const int p = by_size[q++];
         const PairPlan& pp = bp.pairs[p];
         TeaserJob* job = slots[(size_t)half * kGroup + G.count].get();
-        G.rc = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], job, prep_stream, fset);
-        if (G.rc != LGICP_OK) return;
+        const int sub = G.count % n_prep;
+        G.rc = teaser_prepare_device(ctx, feats[pp.src_cloud], feats[pp.tgt_cloud], job, prep_streams[sub], fset, sub);
+        if (G.rc != LGICP_OK) {  // nothing of this group stays in flight behind the error
+          for (int j = 0; j < n_prep; ++j) (void)hipStreamSynchronize(prep_streams[j]);
+          return;
+        }
         bytes += (size_t)job->graph.n * job->graph.words * sizeof(uint64_t);
         G.pair[G.count] = p, G.jobs[G.count] = job, G.guesses[G.count] = pp.guess;
         ++G.count;
       }
-      if (hipStreamSynchronize(prep_stream) != hipSuccess) {
-        G.rc = fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: matches and graphs failed on the device (%s)",
-                    hipGetErrorString(hipGetLastError()));
-        return;
-      }
+      for (int j = 0; j < n_prep; ++j)
+        if (hipStreamSynchronize(prep_streams[j]) != hipSuccess) {
+          G.rc = fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: matches and graphs failed on the device (%s)",
+                      hipGetErrorString(hipGetLastError()));
+          return;
+        }
       for (int j = 0; j < G.count; ++j) teaser_prepare_collect(G.jobs[j]);
       G.ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count();
     };

@@ -416,7 +416,7 @@ int clique_device_max_vertices();
 // matcher's buffers are shared)
 // (fset: whose descriptor-matcher buffers the call uses)
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
-                          TeaserJob* job, hipStream_t st = nullptr, int fset = 0);
+                          TeaserJob* job, hipStream_t st = nullptr, int fset = 0, int sub = 0);
 void teaser_prepare_collect(TeaserJob* job);
 // (st: the stream of the clique search, the context's own when null)
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,

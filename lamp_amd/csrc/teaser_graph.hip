@@ -29,6 +29,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -562,7 +564,7 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   };
   std::vector<Search> S((size_t)P);
   unsigned short* h_pref = reinterpret_cast<unsigned short*>(B.h_up.p + tab_bytes);
-  for (int p = 0; p < P; ++p) {
+  auto orders_of = [&](int p) {
     const int n = tab[p].n;
     Search& s = S[p];
     s.K.resize((size_t)n), s.order.resize((size_t)n);
@@ -581,6 +583,19 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
     next = first;
     unsigned short* pr = h_pref + tab[p].c_off;
     for (int v = n - 1; v >= 0; --v) pr[next[s.K[v]]++] = (unsigned short)v;
+  };
+  {
+    // a few milliseconds of counting sorts for a group of large graphs: graphs side by side on host threads
+    const int nt = std::min(P, (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+    std::atomic<int> next_p{0};
+    auto run = [&] {
+      for (int p; (p = next_p.fetch_add(1)) < P;) orders_of(p);
+    };
+    std::vector<std::thread> pool;
+    if (total_c >= 65536)
+      for (int t = 1; t < nt; ++t) pool.emplace_back(run);
+    run();
+    for (std::thread& t : pool) t.join();
   }
   if (hipMemcpyAsync(B.pref.p, h_pref, sizeof(unsigned short) * total_c, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)  // h_up is rewritten below
