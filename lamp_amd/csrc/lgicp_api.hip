@@ -768,7 +768,11 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     // for one pair as for sixty-four).  Largest pairs first, so that the pairs of a group are of
     // similar size and the buffers of the slots are sized once.
     const bool trace = std::getenv("LGICP_TRACE") != nullptr;  // diagnostics on stderr
-    constexpr int kGroup = 256;
+    constexpr int kGroup = 512;
+    // the first group of a submit has nothing to run beside (its matches and graphs are waited
+    // for), so it is kept small: the pairs with the longest chains, whose search then hides the
+    // preparation of all the others
+    constexpr int kFirstGroup = 64;
     constexpr size_t kGroupBytes = 12ull << 30;  // bit matrices of a group
     // Two sets of slots: while the clique search of one group runs on the context's stream (chains
     // of launches that leave much of the GPU idle in their tails), a helper thread enqueues the
@@ -802,7 +806,8 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
         return;
       }
       size_t bytes = 0;
-      while (q < n_pairs && G.count < kGroup && bytes < kGroupBytes) {
+      const int room = q == 0 ? kFirstGroup : kGroup;
+      while (q < n_pairs && G.count < room && bytes < kGroupBytes) {
         const int p = by_size[q++];
         const PairPlan& pp = bp.pairs[p];
         TeaserJob* job = slots[(size_t)half * kGroup + G.count].get();
