@@ -201,8 +201,9 @@ __global__ __launch_bounds__(SS_THREADS) void sac_score_kernel(const float* __re
         for (int e = 0; e < 4; ++e) {
           const ss_v2f dx = qx[p] - tx[e], dy = qy[p] - ty[e], dz = qz[p] - tz[e];
           const ss_v2f d = (dx * dx + dy * dy) + dz * dz;
-          best[2 * p] = d.x < best[2 * p] ? d.x : best[2 * p];
-          best[2 * p + 1] = d.y < best[2 * p + 1] ? d.y : best[2 * p + 1];
+          // (one v_min_f32 each; like the comparison it replaces, a NaN distance never wins)
+          best[2 * p] = __builtin_fminf(best[2 * p], d.x);
+          best[2 * p + 1] = __builtin_fminf(best[2 * p + 1], d.y);
         }
       }
     }
