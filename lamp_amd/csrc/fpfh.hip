@@ -12,7 +12,12 @@
 // Mapping: the radius is large against the scene, so a neighbourhood holds a sizeable share of
 // the cloud and an exhaustive tiled sweep (same LDS staging as the 1-NN kernel, points plus
 // normals) beats any tree: one lane per surface point, per-lane bin counters in LDS laid out
-// [bin][lane] so that lanes never share a bank.
+// [bin][lane] so that lanes never share a bank.  One lane per point alone would be 64 workgroups
+// for a 16k-point cloud, a wave on every fourth SIMD; the bins are counters, so the sweep of a
+// point is cut into ranges of the surface (gridDim.y) whose counts meet in integer atomics, and
+// the float histogram is made from the totals afterwards: the same numbers in any order.
+#include <algorithm>
+
 #include "lgicp_device.h"
 
 namespace lgicp {
@@ -42,10 +47,14 @@ __device__ __forceinline__ int clamp_bin(float x) {
   return h >= FP_BINS ? FP_BINS - 1 : h;
 }
 
+// counts[i][33] (zeroed by the caller, the float histogram's memory) and nbr[i] receive the range's
+// share of point i's bins and of its neighbour count.  Range blockIdx.y = surface points
+// [blockIdx.y * per_range, (blockIdx.y + 1) * per_range), per_range a multiple of FP_TILE.
 __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ surf,
                                                    const float4* __restrict__ nrm, int n,
                                                    const unsigned char* __restrict__ need,
-                                                   float r2, float* __restrict__ spfh) {
+                                                   float r2, int per_range, int* __restrict__ counts,
+                                                   int* __restrict__ nbr) {
   __shared__ __attribute__((aligned(16))) float tile[6 * FP_TILE];
   __shared__ int cnt[33 * 256];
   const int tid = threadIdx.x;
@@ -61,11 +70,12 @@ __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ su
 #pragma unroll
   for (int b = 0; b < 33; ++b) cnt[b * 256 + tid] = 0;
   int n_nbr = 0;
-  for (int base = 0; base < n; base += FP_TILE) {
+  const int range_end = min(n, (int)(blockIdx.y + 1) * per_range);
+  for (int base = blockIdx.y * per_range; base < range_end; base += FP_TILE) {
     __syncthreads();
     for (int j = tid; j < FP_TILE; j += 256) {
       float4 q = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 0), m = make_float4(0, 0, 0, 0);
-      if (base + j < n) {
+      if (base + j < range_end) {
         q = surf[base + j];
         m = nrm[base + j];
       }
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ su
     }
     __syncthreads();
     if (!live) continue;
-    const int jend = min(FP_TILE, n - base);
+    const int jend = min(FP_TILE, range_end - base);
     for (int j = 0; j < jend; ++j) {
       float dx = tile[j] - p.x, dy = tile[FP_TILE + j] - p.y, dz = tile[2 * FP_TILE + j] - p.z;
       // radius test on the search distance (query - point, x, y, z order)
@@ -122,12 +132,26 @@ __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ su
     }
   }
   if (!live) return;
-  // every admitted pair adds hist_incr = 100 / (k - 1); the reference adds them one by one in
-  // float, here count * incr (differs by float accumulation error only)
-  const float incr = 100.0f / (float)(n_nbr - 1);
-  float* o = spfh + (size_t)i * 33;
+  int* o = counts + (size_t)i * 33;
 #pragma unroll
-  for (int b = 0; b < 33; ++b) o[b] = (float)cnt[b * 256 + tid] * incr;
+  for (int b = 0; b < 33; ++b) {
+    const int c = cnt[b * 256 + tid];
+    if (c) atomicAdd(o + b, c);
+  }
+  if (n_nbr) atomicAdd(nbr + i, n_nbr);
+}
+
+// every admitted pair adds hist_incr = 100 / (k - 1); the reference adds them one by one in
+// float, here count * incr (differs by float accumulation error only).  In place: the counts of
+// a point become its histogram.
+__global__ void spfh_finish_kernel(int n, const unsigned char* __restrict__ need, const int* __restrict__ nbr,
+                                   float* __restrict__ spfh) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * 33) return;
+  const int i = e / 33;
+  if (!need[i]) return;
+  const float incr = 100.0f / (float)(nbr[i] - 1);
+  spfh[e] = (float)reinterpret_cast<const int*>(spfh)[e] * incr;
 }
 
 __global__ __launch_bounds__(256) void fpfh_weight_kernel(const float4* __restrict__ surf, int n,
@@ -173,14 +197,25 @@ __global__ __launch_bounds__(256) void fpfh_weight_kernel(const float4* __restri
 }
 
 hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float4* keys, int n_key,
-                       float r2, unsigned char* need, float* spfh, float* out,
+                       float r2, unsigned char* need, float* spfh, int* nbr, float* out,
                        hipStream_t stream) {
   if (n_key <= 0) return hipSuccess;
   if (n > 0) {
     hipLaunchKernelGGL(fpfh_need_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, surf, n, keys,
                        n_key, r2, need);
-    hipLaunchKernelGGL(spfh_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, surf, nrm, n,
-                       need, r2, spfh);
+    // ranges of the surface so that the sweep fills the GPU (about 2,000 workgroups), each at least
+    // four tiles long
+    const int blocks = (n + 255) / 256;
+    int ranges = std::max(1, std::min((2048 + blocks - 1) / blocks, (n + 4 * FP_TILE - 1) / (4 * FP_TILE)));
+    int per_range = (n + ranges - 1) / ranges;
+    per_range = ((per_range + FP_TILE - 1) / FP_TILE) * FP_TILE;
+    ranges = (n + per_range - 1) / per_range;
+    hipError_t e = hipMemsetAsync(spfh, 0, sizeof(float) * 33 * (size_t)n, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(nbr, 0, sizeof(int) * (size_t)n, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spfh_kernel, dim3(blocks, ranges), dim3(256), 0, stream, surf, nrm, n, need, r2,
+                       per_range, reinterpret_cast<int*>(spfh), nbr);
+    hipLaunchKernelGGL(spfh_finish_kernel, dim3((n * 33 + 255) / 256), dim3(256), 0, stream, n, need, nbr, spfh);
   }
   hipLaunchKernelGGL(fpfh_weight_kernel, dim3(n_key), dim3(256), 0, stream, surf, n, keys, r2,
                      spfh, out);

@@ -11,6 +11,8 @@
 // cloud streaming through LDS; the radius test uses the search distance arithmetic of the 1-NN
 // kernel and FLANN's strict `<`.  Neighbours are summed in ascending index (PCL visits them by
 // ascending distance), so responses can differ from PCL's in the last float bits.
+#include <algorithm>
+
 #include "lgicp_device.h"
 
 namespace lgicp {
@@ -78,9 +80,14 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
   response[i] = r;
 }
 
+// The suppression sweep of a point is cut into ranges of the cloud (gridDim.y; one lane per point
+// alone leaves three SIMDs in four idle on a 16k-point cloud): is_key starts at 1 everywhere (the
+// caller's memset) and every range clears the points it rules out, so all writes are zeros.
+// Range blockIdx.y = points [blockIdx.y * per_range, (blockIdx.y + 1) * per_range), per_range a
+// multiple of HR_TILE.
 __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restrict__ xyz,
                                                          const float* __restrict__ response,
-                                                         int n, float r2, float threshold,
+                                                         int n, float r2, float threshold, int per_range,
                                                          unsigned char* __restrict__ is_key) {
   __shared__ __attribute__((aligned(16))) float tile[4 * HR_TILE];
   const int tid = threadIdx.x;
@@ -93,16 +100,15 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restric
   }
   bool cand = i < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(ri) &&
               !(ri < threshold);
-  if (__syncthreads_count(cand) == 0) {
-    if (i < n) is_key[i] = 0;
-    return;
-  }
-  for (int base = 0; base < n; base += HR_TILE) {
+  if (i < n && !cand) is_key[i] = 0;
+  if (__syncthreads_count(cand) == 0) return;
+  const int range_end = min(n, (int)(blockIdx.y + 1) * per_range);
+  for (int base = blockIdx.y * per_range; base < range_end; base += HR_TILE) {
     __syncthreads();
     for (int j = tid; j < HR_TILE; j += 256) {
       float4 q = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 0);
       float rj = -1.f;
-      if (base + j < n) {
+      if (base + j < range_end) {
         q = xyz[base + j];
         rj = response[base + j];
       }
@@ -113,14 +119,14 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restric
     }
     __syncthreads();
     if (!cand) continue;
-    const int jend = min(HR_TILE, n - base);
+    const int jend = min(HR_TILE, range_end - base);
     for (int j = 0; j < jend; ++j) {
       const float dx = p.x - tile[j], dy = p.y - tile[HR_TILE + j], dz = p.z - tile[2 * HR_TILE + j];
       const float d2 = (dx * dx + dy * dy) + dz * dz;
       if (d2 < r2 && ri < tile[3 * HR_TILE + j]) cand = false;
     }
   }
-  if (i < n) is_key[i] = cand ? 1 : 0;
+  if (i < n && !cand) is_key[i] = 0;
 }
 
 hipError_t launch_harris(const float4* xyz, const float4* nrm, int n, float r2, float threshold,
@@ -128,8 +134,15 @@ hipError_t launch_harris(const float4* xyz, const float4* nrm, int n, float r2, 
   if (n <= 0) return hipSuccess;
   const dim3 grid((n + 255) / 256), block(256);
   hipLaunchKernelGGL(harris_response_kernel, grid, block, 0, stream, xyz, nrm, n, r2, response);
-  hipLaunchKernelGGL(harris_nms_kernel, grid, block, 0, stream, xyz, response, n, r2, threshold,
-                     is_key);
+  const int blocks = (n + 255) / 256;
+  int ranges = std::max(1, std::min((2048 + blocks - 1) / blocks, (n + 4 * HR_TILE - 1) / (4 * HR_TILE)));
+  int per_range = (n + ranges - 1) / ranges;
+  per_range = ((per_range + HR_TILE - 1) / HR_TILE) * HR_TILE;
+  ranges = (n + per_range - 1) / per_range;
+  const hipError_t e = hipMemsetAsync(is_key, 1, (size_t)n, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(harris_nms_kernel, dim3(blocks, ranges), block, 0, stream, xyz, response, n, r2, threshold,
+                     per_range, is_key);
   return hipGetLastError();
 }
 
