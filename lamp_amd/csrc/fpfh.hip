@@ -88,18 +88,16 @@ __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ su
     }
     __syncthreads();
     if (!live) continue;
-    const int jend = min(FP_TILE, range_end - base);
-    for (int j = 0; j < jend; ++j) {
+    // Four candidates per step (one 16-byte LDS read per coordinate, four independent chains of the
+    // radius test on the search distance: query - point, x, y, z order) and a branch only when one of
+    // them is a neighbour; the tail of the last tile holds padding points, never within the radius.
+    auto neighbour = [&](int j) {
       float dx = tile[j] - p.x, dy = tile[FP_TILE + j] - p.y, dz = tile[2 * FP_TILE + j] - p.z;
-      // radius test on the search distance (query - point, x, y, z order)
-      const float ex = p.x - tile[j], ey = p.y - tile[FP_TILE + j], ez = p.z - tile[2 * FP_TILE + j];
-      const float d2 = (ex * ex + ey * ey) + ez * ez;
-      if (!(d2 < r2)) continue;
       ++n_nbr;
-      if (base + j == i) continue;
+      if (base + j == i) return;
       // pcl::computePairFeatures(p1 = this point, p2 = neighbour)
       const float f4 = sqrtf(dx * dx + dy * dy + dz * dz);
-      if (f4 == 0.0f) continue;
+      if (f4 == 0.0f) return;
       float n1x = a.x, n1y = a.y, n1z = a.z;
       float n2x = tile[3 * FP_TILE + j], n2y = tile[4 * FP_TILE + j], n2z = tile[5 * FP_TILE + j];
       const float angle1 = (n1x * dx + n1y * dy + n1z * dz) / f4;
@@ -117,7 +115,7 @@ __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ su
       }
       float vx = dy * n1z - dz * n1y, vy = dz * n1x - dx * n1z, vz = dx * n1y - dy * n1x;
       const float v_norm = sqrtf(vx * vx + vy * vy + vz * vz);
-      if (v_norm == 0.0f) continue;
+      if (v_norm == 0.0f) return;
       const float s = 1.0f / v_norm;
       vx *= s, vy *= s, vz *= s;
       const float wx = n1y * vz - n1z * vy, wy = n1z * vx - n1x * vz, wz = n1x * vy - n1y * vx;
@@ -129,6 +127,23 @@ __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ su
       cnt[b1 * 256 + tid] += 1;
       cnt[(FP_BINS + b2) * 256 + tid] += 1;
       cnt[(2 * FP_BINS + b3) * 256 + tid] += 1;
+    };
+    const int jend = (min(FP_TILE, range_end - base) + 3) & ~3;
+    for (int j = 0; j < jend; j += 4) {
+      const float4 X = *reinterpret_cast<const float4*>(tile + j);
+      const float4 Y = *reinterpret_cast<const float4*>(tile + FP_TILE + j);
+      const float4 Z = *reinterpret_cast<const float4*>(tile + 2 * FP_TILE + j);
+      const float tx[4] = {X.x, X.y, X.z, X.w}, ty[4] = {Y.x, Y.y, Y.z, Y.w}, tz[4] = {Z.x, Z.y, Z.z, Z.w};
+      bool in[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ex = p.x - tx[e], ey = p.y - ty[e], ez = p.z - tz[e];
+        in[e] = (ex * ex + ey * ey) + ez * ez < r2;
+      }
+      if (!(in[0] || in[1] || in[2] || in[3])) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (in[e]) neighbour(j + e);
     }
   }
   if (!live) return;

@@ -46,21 +46,37 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
       tile[5 * HR_TILE + j] = m.z;
     }
     __syncthreads();
-    const int jend = min(HR_TILE, n - base);
-    for (int j = 0; j < jend; ++j) {
-      const float dx = p.x - tile[j], dy = p.y - tile[HR_TILE + j], dz = p.z - tile[2 * HR_TILE + j];
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      if (!(d2 < r2)) continue;
-      const float mx = tile[3 * HR_TILE + j], my = tile[4 * HR_TILE + j], mz = tile[5 * HR_TILE + j];
-      if (!isfinite(mx)) continue;
-      xx += mx * mx;
-      xy += my * mx;
-      xz += mz * mx;
-      yx += mx * my;
-      yy += my * my;
-      yz += mz * my;
-      zz += mz * mz;
-      ++count;
+    // Four candidates per step (one 16-byte LDS read per coordinate, four independent distance
+    // chains) and a branch only when one of them lies within the radius, which few do; the
+    // admitted ones are added in ascending index as before.  The tail of the last tile holds
+    // padding points, which are never within the radius.
+    const int jend = (min(HR_TILE, n - base) + 3) & ~3;
+    for (int j = 0; j < jend; j += 4) {
+      const float4 X = *reinterpret_cast<const float4*>(tile + j);
+      const float4 Y = *reinterpret_cast<const float4*>(tile + HR_TILE + j);
+      const float4 Z = *reinterpret_cast<const float4*>(tile + 2 * HR_TILE + j);
+      const float tx[4] = {X.x, X.y, X.z, X.w}, ty[4] = {Y.x, Y.y, Y.z, Y.w}, tz[4] = {Z.x, Z.y, Z.z, Z.w};
+      bool in[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dx = p.x - tx[e], dy = p.y - ty[e], dz = p.z - tz[e];
+        in[e] = (dx * dx + dy * dy) + dz * dz < r2;
+      }
+      if (!(in[0] || in[1] || in[2] || in[3])) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!in[e]) continue;
+        const float mx = tile[3 * HR_TILE + j + e], my = tile[4 * HR_TILE + j + e], mz = tile[5 * HR_TILE + j + e];
+        if (!isfinite(mx)) continue;
+        xx += mx * mx;
+        xy += my * mx;
+        xz += mz * mx;
+        yx += mx * my;
+        yy += my * my;
+        yz += mz * my;
+        zz += mz * mz;
+        ++count;
+      }
     }
   }
   if (i >= n) return;
