@@ -138,6 +138,31 @@ def test_c4_group_results_do_not_depend_on_the_grouping():
         assert np.array_equal(a["T_icp"], b["T_icp"]) and a["status"] == b["status"]
 
 
+def test_c4_large_submit_goes_through_several_groups():
+    """A TEASERPP submit takes its pairs in groups (the 64 with the most matches first, then up to
+    512 at a time, each group prepared on a helper thread beside the search of the one before).  600
+    pairs are three groups; cut into submits of 50, which are one group each, they must come out the
+    same, bit for bit."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=600, keyframes=16, points=2048)
+    cands = work.candidates()
+    c = capi.Context(init_method=capi.INIT_TEASERPP, harris_radius=0.6, transform_thresholding=0)
+    try:
+        work.register(c)
+        whole = [capi.result_to_dict(r) for r in c.submit(cands)]
+        parts = []
+        for k in range(0, len(cands), 50):
+            parts += [capi.result_to_dict(r) for r in c.submit(cands[k:k + 50])]
+    finally:
+        c.close()
+    assert len(whole) == len(parts) == 600
+    assert sum(d["init_fitness"] > 0 for d in whole) >= 300     # TEASER++ was used, not just the guess
+    for a, b in zip(whole, parts):
+        assert a["init_fitness"] == b["init_fitness"] and a["status"] == b["status"]
+        assert np.array_equal(a["T_init"], b["T_init"]) and np.array_equal(a["T_icp"], b["T_icp"])
+
+
 @pytest.mark.parametrize("method", ["TEASERPP", "FEATURES"])
 def test_c4_submits_side_by_side_equal_submits_in_turn(method):
     """A context with a feature-based initialisation takes two submits at a time
