@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void match_points_kernel(const int* __restrict
 // not), so every pair is tested once and both words leave in one store each.
 __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __restrict__ src,
                                                                 const double* __restrict__ dst,
-                                                                int n, int words, double beta,
+                                                                int n, int words, int k, double beta,
                                                                 unsigned long long* __restrict__ bits) {
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int w = blockIdx.x;                // column block
@@ -268,18 +268,26 @@ __global__ __launch_bounds__(256) void consistency_graph_kernel(const double* __
   const double djx = dst[3 * jj], djy = dst[3 * jj + 1], djz = dst[3 * jj + 2];
   const int rows = min(64, n - i0);
   unsigned long long mine = 0, mirrored = 0;
+  double root_a = 0;
   for (int r = 0; r < rows; ++r) {
     const int i = i0 + r;
-    const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+    double e;
+    // matches i = q k .. q k + k - 1 pair the same source keypoint q with its k nearest targets:
+    // their source coordinates are the same numbers, and so is the source-side distance to match j
+    if (r == 0 || i % k == 0) {  // wave-uniform
+      const double sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+      double a = 0;
+      e = sjx - sx, a += e * e;
+      e = sjy - sy, a += e * e;
+      e = sjz - sz, a += e * e;
+      root_a = sqrt(a);
+    }
     const double dx = dst[3 * i], dy = dst[3 * i + 1], dz = dst[3 * i + 2];
-    double e, a = 0, c = 0;
-    e = sjx - sx, a += e * e;
-    e = sjy - sy, a += e * e;
-    e = sjz - sz, a += e * e;
+    double c = 0;
     e = djx - dx, c += e * e;
     e = djy - dy, c += e * e;
     e = djz - dz, c += e * e;
-    const bool ok = jv && j != i && fabs(sqrt(a) - sqrt(c)) <= beta;
+    const bool ok = jv && j != i && fabs(root_a - sqrt(c)) <= beta;
     const unsigned long long m = __ballot(ok);
     if (lane == r) mine = m;
     mirrored |= ok ? 1ull << r : 0ull;
@@ -474,7 +482,7 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
   hipLaunchKernelGGL(lgicp::match_points_kernel, dim3((n + 255) / 256), dim3(256), 0, st, md.nn.p, src.d_kxyz,
                      tgt.d_kxyz, n_src, k, d_s, d_d);
   hipLaunchKernelGGL(lgicp::consistency_graph_kernel, dim3(g.words, (n + 255) / 256), dim3(256), 0, st, d_s,
-                     d_d, n, g.words, 2.0 * prm.noise_bound * std::sqrt(prm.cbar2), job->d_bits.p);
+                     d_d, n, g.words, k, 2.0 * prm.noise_bound * std::sqrt(prm.cbar2), job->d_bits.p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(job->h_sd, job->d_sd.p, sd_bytes, hipMemcpyDeviceToHost, st));
   // The graph stays on the device: core numbers and the clique search run there
