@@ -23,10 +23,14 @@ namespace lgicp {
 
 // nn[i][0..k) = indices of the k nearest target descriptors of source descriptor i.
 // One lane per source descriptor (33 floats in registers); the target descriptors stream
-// through LDS in tiles of FK_TILE, padded to 36 floats so that a descriptor is read back with
-// nine wave-uniform (broadcast) ds_read_b128.
+// through LDS in tiles of FK_TILE, two at a time: a pair of targets is stored interleaved (bin b of
+// both side by side, 72 floats per pair), so that seventeen wave-uniform (broadcast) ds_read_b128
+// bring both and every subtraction, multiplication and addition of the two distances is one packed
+// instruction - each distance still the sum over the bins in ascending order, every operation
+// rounded separately.
 constexpr int FK_TILE = 64;
-constexpr int FK_STRIDE = 36;
+constexpr int FK_PAIR = 72;
+typedef float fk_v2f __attribute__((ext_vector_type(2)));
 
 //
 // The targets are cut into gridDim.y ranges of `per_split` (a few hundred source descriptors
@@ -40,57 +44,64 @@ __global__ __launch_bounds__(128) void feature_knn_kernel(const float* __restric
                                                           int n_tgt_all, int per_split, int k,
                                                           float* __restrict__ part_d,
                                                           int* __restrict__ part_i) {
-  __shared__ __attribute__((aligned(16))) float tile[FK_TILE * FK_STRIDE];
+  __shared__ __attribute__((aligned(16))) float tile[(FK_TILE / 2) * FK_PAIR];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  float f[36];
+  float f[33];
 #pragma unroll
-  for (int b = 0; b < 36; ++b) f[b] = (b < 33 && i < n_src) ? src_feat[(size_t)i * 33 + b] : 0.f;
+  for (int b = 0; b < 33; ++b) f[b] = i < n_src ? src_feat[(size_t)i * 33 + b] : 0.f;
   float bd[8];
   int bi[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) bd[s] = __builtin_inff(), bi[s] = -1;
+  auto offer = [&](float d, int j) {
+    float worst = bd[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s)
+      if (s < k) worst = bd[s];
+    if (d < worst) {
+      float cd = d;
+      int ci = j;
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < k) {
+          const bool lt = cd < bd[s];
+          const float td = lt ? bd[s] : cd;
+          const int ti = lt ? bi[s] : ci;
+          bd[s] = lt ? cd : bd[s];
+          bi[s] = lt ? ci : bi[s];
+          cd = td;
+          ci = ti;
+        }
+    }
+  };
   const int j_begin = blockIdx.y * per_split;
   const int n_tgt = min(n_tgt_all, j_begin + per_split);
   for (int j0 = j_begin; j0 < n_tgt; j0 += FK_TILE) {
     __syncthreads();
     const int cnt = min(FK_TILE, n_tgt - j0);
-    for (int e = threadIdx.x; e < cnt * 33; e += blockDim.x)
-      tile[(e / 33) * FK_STRIDE + e % 33] = tgt_feat[(size_t)j0 * 33 + e];
+    for (int e = threadIdx.x; e < cnt * 33; e += blockDim.x) {
+      const int jj = e / 33, b = e % 33;
+      tile[(jj >> 1) * FK_PAIR + 2 * b + (jj & 1)] = tgt_feat[(size_t)j0 * 33 + e];
+    }
     __syncthreads();
-    for (int jj = 0; jj < cnt; ++jj) {
-      const float4* t4 = reinterpret_cast<const float4*>(tile + jj * FK_STRIDE);
-      float t[36];
+    for (int jj = 0; jj < cnt; jj += 2) {
+      const float4* t4 = reinterpret_cast<const float4*>(tile + (jj >> 1) * FK_PAIR);
+      float t[68];
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
+      for (int q = 0; q < 17; ++q) {
         const float4 v = t4[q];
         t[4 * q] = v.x, t[4 * q + 1] = v.y, t[4 * q + 2] = v.z, t[4 * q + 3] = v.w;
       }
-      float d = 0;
+      fk_v2f d = {0.f, 0.f};
 #pragma unroll
       for (int b = 0; b < 33; ++b) {
-        const float e = f[b] - t[b];
+        const fk_v2f fb = {f[b], f[b]}, tb = {t[2 * b], t[2 * b + 1]};
+        const fk_v2f e = fb - tb;
         d += e * e;
       }
-      const int j = j0 + jj;
-      float worst = bd[0];
-#pragma unroll
-      for (int s = 1; s < 8; ++s)
-        if (s < k) worst = bd[s];
-      if (d < worst) {
-        float cd = d;
-        int ci = j;
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-          if (s < k) {
-            const bool lt = cd < bd[s];
-            const float td = lt ? bd[s] : cd;
-            const int ti = lt ? bi[s] : ci;
-            bd[s] = lt ? cd : bd[s];
-            bi[s] = lt ? ci : bi[s];
-            cd = td;
-            ci = ti;
-          }
-      }
+      offer(d.x, j0 + jj);
+      // (the partner slot of an odd tile's last target holds stale numbers: never offered)
+      if (jj + 1 < cnt) offer(d.y, j0 + jj + 1);
     }
   }
   if (i < n_src) {
