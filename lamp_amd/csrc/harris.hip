@@ -19,17 +19,30 @@ namespace lgicp {
 
 static constexpr int HR_TILE = 512;
 
+// One lane per candidate, not per point: a wave owns HR_PW points at a time, its 64 lanes test 64
+// candidates of the tile in LDS against each of them, and the few that lie within the radius (a
+// ballot) are added to the point's sums one after the other in ascending index - the order the
+// sums had with one lane per point, so the responses are the same floats, but a 16k-point cloud is
+// 1,024 workgroups instead of 64.  The sums of a point are wave-uniform values.
+static constexpr int HR_PW = 4;
 __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __restrict__ xyz,
                                                               const float4* __restrict__ nrm,
                                                               int n, float r2,
                                                               float* __restrict__ response) {
   __shared__ __attribute__((aligned(16))) float tile[6 * HR_TILE];
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * 256 + tid;
-  float4 p = make_float4(__builtin_nanf(""), 0, 0, 0);
-  if (i < n) p = xyz[i];
-  float xx = 0, xy = 0, xz = 0, yx = 0, yy = 0, yz = 0, zz = 0;
-  unsigned count = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = (blockIdx.x * 4 + wave) * HR_PW;  // this wave's points: i0 .. i0 + HR_PW - 1
+  float px[HR_PW], py[HR_PW], pz[HR_PW];
+  float xx[HR_PW], xy[HR_PW], xz[HR_PW], yx[HR_PW], yy[HR_PW], yz[HR_PW], zz[HR_PW];
+  unsigned count[HR_PW];
+#pragma unroll
+  for (int q = 0; q < HR_PW; ++q) {
+    float4 p = make_float4(__builtin_nanf(""), 0, 0, 0);
+    if (i0 + q < n) p = xyz[i0 + q];
+    px[q] = p.x, py[q] = p.y, pz[q] = p.z;
+    xx[q] = xy[q] = xz[q] = yx[q] = yy[q] = yz[q] = zz[q] = 0.f;
+    count[q] = 0;
+  }
   for (int base = 0; base < n; base += HR_TILE) {
     __syncthreads();
     for (int j = tid; j < HR_TILE; j += 256) {
@@ -46,54 +59,50 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
       tile[5 * HR_TILE + j] = m.z;
     }
     __syncthreads();
-    // Four candidates per step (one 16-byte LDS read per coordinate, four independent distance
-    // chains) and a branch only when one of them lies within the radius, which few do; the
-    // admitted ones are added in ascending index as before.  The tail of the last tile holds
-    // padding points, which are never within the radius.
-    const int jend = (min(HR_TILE, n - base) + 3) & ~3;
-    for (int j = 0; j < jend; j += 4) {
-      const float4 X = *reinterpret_cast<const float4*>(tile + j);
-      const float4 Y = *reinterpret_cast<const float4*>(tile + HR_TILE + j);
-      const float4 Z = *reinterpret_cast<const float4*>(tile + 2 * HR_TILE + j);
-      const float tx[4] = {X.x, X.y, X.z, X.w}, ty[4] = {Y.x, Y.y, Y.z, Y.w}, tz[4] = {Z.x, Z.y, Z.z, Z.w};
-      bool in[4];
+    const int jend = min(HR_TILE, n - base);  // (the rest of the tile is padding, never within the radius)
+    for (int c = 0; c < jend; c += 64) {
+      const float tx = tile[c + lane], ty = tile[HR_TILE + c + lane], tz = tile[2 * HR_TILE + c + lane];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float dx = p.x - tx[e], dy = p.y - ty[e], dz = p.z - tz[e];
-        in[e] = (dx * dx + dy * dy) + dz * dz < r2;
-      }
-      if (!(in[0] || in[1] || in[2] || in[3])) continue;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (!in[e]) continue;
-        const float mx = tile[3 * HR_TILE + j + e], my = tile[4 * HR_TILE + j + e], mz = tile[5 * HR_TILE + j + e];
-        if (!isfinite(mx)) continue;
-        xx += mx * mx;
-        xy += my * mx;
-        xz += mz * mx;
-        yx += mx * my;
-        yy += my * my;
-        yz += mz * my;
-        zz += mz * mz;
-        ++count;
+      for (int q = 0; q < HR_PW; ++q) {
+        const float dx = px[q] - tx, dy = py[q] - ty, dz = pz[q] - tz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        unsigned long long m = __ballot(d2 < r2);
+        while (m) {  // wave-uniform: the neighbours among these 64, ascending
+          const int j = c + __builtin_ctzll(m);
+          m &= m - 1;
+          const float mx = tile[3 * HR_TILE + j], my = tile[4 * HR_TILE + j], mz = tile[5 * HR_TILE + j];
+          if (!isfinite(mx)) continue;
+          xx[q] += mx * mx;
+          xy[q] += my * mx;
+          xz[q] += mz * mx;
+          yx[q] += mx * my;
+          yy[q] += my * my;
+          yz[q] += mz * my;
+          zz[q] += mz * mz;
+          ++count[q];
+        }
       }
     }
   }
-  if (i >= n) return;
-  float r = 0.f;
-  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-    if (count > 0) {
-      const float c = (float)count;
-      xx = xx / c, xy = xy / c, xz = xz / c, yx = yx / c, yy = yy / c, yz = yz / c, zz = zz / c;
+#pragma unroll
+  for (int q = 0; q < HR_PW; ++q) {
+    const int i = i0 + q;
+    if (i >= n) break;
+    float r = 0.f;
+    float sxx = xx[q], sxy = xy[q], sxz = xz[q], syy = yy[q], syz = yz[q], szz = zz[q];
+    if (isfinite(px[q]) && isfinite(py[q]) && isfinite(pz[q])) {
+      if (count[q] > 0) {
+        const float cf = (float)count[q];
+        sxx = sxx / cf, sxy = sxy / cf, sxz = sxz / cf, syy = syy / cf, syz = syz / cf, szz = szz / cf;
+      }
+      const float trace = sxx + syy + szz;
+      if (trace != 0) {
+        const float det = sxx * syy * szz + 2.0f * sxy * sxz * syz - sxz * sxz * syy - sxy * sxy * szz - syz * syz * sxx;
+        r = 0.04f + det - 0.04f * trace * trace;
+      }
     }
-    (void)yx;
-    const float trace = xx + yy + zz;
-    if (trace != 0) {
-      const float det = xx * yy * zz + 2.0f * xy * xz * yz - xz * xz * yy - xy * xy * zz - yz * yz * xx;
-      r = 0.04f + det - 0.04f * trace * trace;
-    }
+    if (lane == 0) response[i] = r;
   }
-  response[i] = r;
 }
 
 // The suppression sweep of a point is cut into ranges of the cloud (gridDim.y; one lane per point
@@ -149,7 +158,8 @@ hipError_t launch_harris(const float4* xyz, const float4* nrm, int n, float r2, 
                          float* response, unsigned char* is_key, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   const dim3 grid((n + 255) / 256), block(256);
-  hipLaunchKernelGGL(harris_response_kernel, grid, block, 0, stream, xyz, nrm, n, r2, response);
+  hipLaunchKernelGGL(harris_response_kernel, dim3((n + 4 * HR_PW - 1) / (4 * HR_PW)), block, 0, stream, xyz, nrm, n, r2,
+                     response);
   const int blocks = (n + 255) / 256;
   int ranges = std::max(1, std::min((2048 + blocks - 1) / blocks, (n + 4 * HR_TILE - 1) / (4 * HR_TILE)));
   int per_range = (n + ranges - 1) / ranges;
