@@ -228,10 +228,10 @@ hipError_t launch_normals_knn(const float4* xyz, int n, int n_pad, int k, float4
 hipError_t launch_normals_radius(const float4* xyz, int n, float r2, float4* normals_curv,
                                  hipStream_t stream);
 
-// FPFH at n_key keypoints over a surface of n points (radius^2 = r2); need[n], spfh[n*33], nbr[n]
+// FPFH at n_key keypoints over a surface of n points (radius^2 = r2); need[n], spfh[n*33]
 // are scratch, out is [n_key][33]
 hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float4* keys, int n_key,
-                       float r2, unsigned char* need, float* spfh, int* nbr, float* out, hipStream_t stream);
+                       float r2, unsigned char* need, float* spfh, float* out, hipStream_t stream);
 
 // Harris3D response + non-maxima suppression (radius^2 = r2); response[n], is_key[n]
 hipError_t launch_harris(const float4* xyz, const float4* nrm, int n, float r2, float threshold,

@@ -369,10 +369,9 @@ struct TeaserJob {
 // by side on different streams), reused from cloud to cloud
 struct FeatureScratch {
   DevBuf<float> resp, spfh;
-  DevBuf<int> nbr;
   DevBuf<unsigned char> key, need;
   DevBuf<float4> kp;
-  void release() { resp.release(), spfh.release(), nbr.release(), key.release(), need.release(), kp.release(); }
+  void release() { resp.release(), spfh.release(), key.release(), need.release(), kp.release(); }
 };
 constexpr int FEATURE_LANES = 4;
 // buffers of the descriptor matcher, reused from pair to pair (work of successive pairs is

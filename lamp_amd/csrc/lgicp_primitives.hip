@@ -245,12 +245,11 @@ int lgicp_fpfh(lgicp_ctx* ctx, const float* surface_xyz, const float* surface_no
   float4* d_k = upload_points(d, keypoints_xyz, n_key, (int)n_key, 1.f);
   unsigned char* d_need = d.alloc<unsigned char>(n);
   float* d_spfh = d.alloc<float>(n * 33);
-  int* d_nbr = d.alloc<int>(n);
   float* d_out = d.alloc<float>(n_key * 33);
-  if (!d_s || !d_n || !d_k || !d_need || !d_spfh || !d_nbr || !d_out)
+  if (!d_s || !d_n || !d_k || !d_need || !d_spfh || !d_out)
     return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
   HIP_TRY(ctx, launch_fpfh(d_s, d_n, (int)n, d_k, (int)n_key, (float)(radius * radius), d_need,
-                           d_spfh, d_nbr, d_out, ctx->stream));
+                           d_spfh, d_out, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * n_key * 33, hipMemcpyDeviceToHost,
                               ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -450,7 +449,7 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
     out->xyz[3 * q] = kp[q].x, out->xyz[3 * q + 1] = kp[q].y, out->xyz[3 * q + 2] = kp[q].z;
   }
   const bool scratch_ok = d.kp.reserve(k) == hipSuccess && d.need.reserve((size_t)n) == hipSuccess &&
-                          d.spfh.reserve((size_t)n * 33) == hipSuccess && d.nbr.reserve((size_t)n) == hipSuccess;
+                          d.spfh.reserve((size_t)n * 33) == hipSuccess;
   float4* d_kp = scratch_ok ? d.kp.p : nullptr;
   unsigned char* d_need = d.need.p;
   float* d_spfh = d.spfh.p;
@@ -462,7 +461,7 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   HIP_TRY(ctx, hipMemcpyAsync(d_out + 33 * k, out->xyz.data(), sizeof(float) * 3 * k, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp.data(), sizeof(float4) * k, hipMemcpyHostToDevice, st));
   const float fr2 = (float)(cfg.sac_features_radius * cfg.sac_features_radius);
-  HIP_TRY(ctx, launch_fpfh(d_xyz, d_nrm, n, d_kp, (int)k, fr2, d_need, d_spfh, d.nbr.p, d_out, st));
+  HIP_TRY(ctx, launch_fpfh(d_xyz, d_nrm, n, d_kp, (int)k, fr2, d_need, d_spfh, d_out, st));
   out->feat.resize(33 * k);
   HIP_TRY(ctx, hipMemcpyAsync(out->feat.data(), d_out, sizeof(float) * 33 * k, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
