@@ -7,10 +7,12 @@
 // normals only); a point is a keypoint when its response is finite, >= threshold and no
 // neighbour within the radius has a strictly larger response.
 //
-// Mapping: two exhaustive tiled sweeps (response, then suppression), one lane per point, the
-// cloud streaming through LDS; the radius test uses the search distance arithmetic of the 1-NN
-// kernel and FLANN's strict `<`.  Neighbours are summed in ascending index (PCL visits them by
-// ascending distance), so responses can differ from PCL's in the last float bits.
+// Mapping: two exhaustive tiled sweeps (response, then suppression) with the cloud streaming
+// through LDS; the radius test uses the search distance arithmetic of the 1-NN kernel and FLANN's
+// strict `<`.  The response sweep gives a wave four points and a lane a candidate, the suppression
+// sweep a lane a point and a workgroup a range of the cloud (see the kernels).  Neighbours are summed
+// in ascending index (PCL visits them by ascending distance), so responses can differ from PCL's in
+// the last float bits.
 #include <algorithm>
 
 #include "lgicp_device.h"
