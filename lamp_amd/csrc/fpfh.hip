@@ -26,20 +26,24 @@ namespace lgicp {
 static constexpr int FP_TILE = 512;
 static constexpr int FP_BINS = 11;
 
+// need[j] = 1 for every surface point within the radius of some keypoint.  need starts at zero (the
+// caller's memset); workgroup (x, y) looks at the keypoints of range y only and writes ones, so the
+// ranges meet in any order.
 __global__ void fpfh_need_kernel(const float4* __restrict__ surf, int n,
-                                 const float4* __restrict__ keys, int n_key, float r2,
+                                 const float4* __restrict__ keys, int n_key, int per_range, float r2,
                                  unsigned char* __restrict__ need) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const float4 p = surf[j];
-  unsigned char f = 0;
-  for (int k = 0; k < n_key; ++k) {
+  bool f = false;
+  const int k_end = min(n_key, (int)(blockIdx.y + 1) * per_range);
+  for (int k = blockIdx.y * per_range; k < k_end; ++k) {
     const float4 q = keys[k];  // wave-uniform
     const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
     const float d = (dx * dx + dy * dy) + dz * dz;
-    if (d < r2) f = 1;
+    if (d < r2) f = true;
   }
-  need[j] = f;
+  if (f) need[j] = 1;
 }
 
 __device__ __forceinline__ int clamp_bin(float x) {
@@ -209,11 +213,17 @@ hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float
                        hipStream_t stream) {
   if (n_key <= 0) return hipSuccess;
   if (n > 0) {
-    hipLaunchKernelGGL(fpfh_need_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, surf, n, keys,
-                       n_key, r2, need);
     // (rows of points that need no SPFH stay zero)
-    const hipError_t e = hipMemsetAsync(spfh, 0, sizeof(float) * 33 * (size_t)n, stream);
+    hipError_t e = hipMemsetAsync(spfh, 0, sizeof(float) * 33 * (size_t)n, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(need, 0, (size_t)n, stream);
     if (e != hipSuccess) return e;
+    // ranges of the keypoints so that the launch fills the GPU (about 2,000 workgroups)
+    const int blocks = (n + 255) / 256;
+    int ranges = std::max(1, std::min((2048 + blocks - 1) / blocks, (n_key + 255) / 256));
+    const int per_range = (n_key + ranges - 1) / ranges;
+    ranges = (n_key + per_range - 1) / per_range;
+    hipLaunchKernelGGL(fpfh_need_kernel, dim3(blocks, ranges), dim3(256), 0, stream, surf, n, keys, n_key,
+                       per_range, r2, need);
     hipLaunchKernelGGL(spfh_kernel, dim3((n + 4 * SP_PW - 1) / (4 * SP_PW)), dim3(256), 0, stream, surf, nrm, n,
                        need, r2, spfh);
   }
