@@ -9,8 +9,8 @@
 //
 // Mapping: two exhaustive tiled sweeps (response, then suppression) with the cloud streaming
 // through LDS; the radius test uses the search distance arithmetic of the 1-NN kernel and FLANN's
-// strict `<`.  The response sweep gives a wave four points and a lane a candidate, the suppression
-// sweep a lane a point and a workgroup a range of the cloud (see the kernels).  Neighbours are summed
+// strict `<`.  Both sweeps give a wave four points at a time and a lane a candidate (see the
+// kernels).  Neighbours are summed
 // in ascending index (PCL visits them by ascending distance), so responses can differ from PCL's in
 // the last float bits.
 #include <algorithm>
@@ -107,35 +107,37 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
   }
 }
 
-// The suppression sweep of a point is cut into ranges of the cloud (gridDim.y; one lane per point
-// alone leaves three SIMDs in four idle on a 16k-point cloud): is_key starts at 1 everywhere (the
-// caller's memset) and every range clears the points it rules out, so all writes are zeros.
-// Range blockIdx.y = points [blockIdx.y * per_range, (blockIdx.y + 1) * per_range), per_range a
-// multiple of HR_TILE.
+// Suppression, one lane per candidate like the response sweep: a wave owns HR_PW points at a time,
+// its 64 lanes test 64 candidates of the tile against each, and a point is done with as soon as one
+// neighbour with a strictly larger response has shown up (most points are, early in the sweep); a
+// wave whose points are all done only keeps the workgroup's barriers company.
 __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restrict__ xyz,
                                                          const float* __restrict__ response,
-                                                         int n, float r2, float threshold, int per_range,
+                                                         int n, float r2, float threshold,
                                                          unsigned char* __restrict__ is_key) {
   __shared__ __attribute__((aligned(16))) float tile[4 * HR_TILE];
-  const int tid = threadIdx.x;
-  const int i = blockIdx.x * 256 + tid;
-  float4 p = make_float4(__builtin_nanf(""), 0, 0, 0);
-  float ri = -1.f;
-  if (i < n) {
-    p = xyz[i];
-    ri = response[i];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = (blockIdx.x * 4 + wave) * HR_PW;
+  float px[HR_PW], py[HR_PW], pz[HR_PW], ri[HR_PW];
+  bool cand[HR_PW];
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < HR_PW; ++q) {
+    float4 p = make_float4(__builtin_nanf(""), 0, 0, 0);
+    ri[q] = -1.f;
+    if (i0 + q < n) p = xyz[i0 + q], ri[q] = response[i0 + q];
+    px[q] = p.x, py[q] = p.y, pz[q] = p.z;
+    cand[q] = i0 + q < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(ri[q]) &&
+              !(ri[q] < threshold);
+    any = any || cand[q];
   }
-  bool cand = i < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(ri) &&
-              !(ri < threshold);
-  if (i < n && !cand) is_key[i] = 0;
-  if (__syncthreads_count(cand) == 0) return;
-  const int range_end = min(n, (int)(blockIdx.y + 1) * per_range);
-  for (int base = blockIdx.y * per_range; base < range_end; base += HR_TILE) {
+  const bool block_any = __syncthreads_count(any) != 0;
+  for (int base = 0; block_any && base < n; base += HR_TILE) {
     __syncthreads();
     for (int j = tid; j < HR_TILE; j += 256) {
       float4 q = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 0);
       float rj = -1.f;
-      if (base + j < range_end) {
+      if (base + j < n) {
         q = xyz[base + j];
         rj = response[base + j];
       }
@@ -145,32 +147,33 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restric
       tile[3 * HR_TILE + j] = rj;
     }
     __syncthreads();
-    if (!cand) continue;
-    const int jend = min(HR_TILE, range_end - base);
-    for (int j = 0; j < jend; ++j) {
-      const float dx = p.x - tile[j], dy = p.y - tile[HR_TILE + j], dz = p.z - tile[2 * HR_TILE + j];
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      if (d2 < r2 && ri < tile[3 * HR_TILE + j]) cand = false;
+    if (!(cand[0] || cand[1] || cand[2] || cand[3])) continue;  // wave-uniform
+    const int jend = min(HR_TILE, n - base);  // (the rest of the tile is padding, never within the radius)
+    for (int c = 0; c < jend; c += 64) {
+      const float tx = tile[c + lane], ty = tile[HR_TILE + c + lane], tz = tile[2 * HR_TILE + c + lane];
+      const float rj = tile[3 * HR_TILE + c + lane];
+#pragma unroll
+      for (int q = 0; q < HR_PW; ++q) {
+        if (!cand[q]) continue;  // wave-uniform
+        const float dx = px[q] - tx, dy = py[q] - ty, dz = pz[q] - tz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (__ballot(d2 < r2 && ri[q] < rj)) cand[q] = false;
+      }
     }
   }
-  if (i < n && !cand) is_key[i] = 0;
+#pragma unroll
+  for (int q = 0; q < HR_PW; ++q)
+    if (lane == 0 && i0 + q < n) is_key[i0 + q] = cand[q] ? 1 : 0;
 }
 
 hipError_t launch_harris(const float4* xyz, const float4* nrm, int n, float r2, float threshold,
                          float* response, unsigned char* is_key, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  const dim3 grid((n + 255) / 256), block(256);
+  const dim3 block(256);
   hipLaunchKernelGGL(harris_response_kernel, dim3((n + 4 * HR_PW - 1) / (4 * HR_PW)), block, 0, stream, xyz, nrm, n, r2,
                      response);
-  const int blocks = (n + 255) / 256;
-  int ranges = std::max(1, std::min((2048 + blocks - 1) / blocks, (n + 4 * HR_TILE - 1) / (4 * HR_TILE)));
-  int per_range = (n + ranges - 1) / ranges;
-  per_range = ((per_range + HR_TILE - 1) / HR_TILE) * HR_TILE;
-  ranges = (n + per_range - 1) / per_range;
-  const hipError_t e = hipMemsetAsync(is_key, 1, (size_t)n, stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(harris_nms_kernel, dim3(blocks, ranges), block, 0, stream, xyz, response, n, r2, threshold,
-                     per_range, is_key);
+  hipLaunchKernelGGL(harris_nms_kernel, dim3((n + 4 * HR_PW - 1) / (4 * HR_PW)), block, 0, stream, xyz, response, n, r2,
+                     threshold, is_key);
   return hipGetLastError();
 }
 
