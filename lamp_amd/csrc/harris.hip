@@ -25,7 +25,9 @@ static constexpr int HR_TILE = 512;
 // candidates of the tile in LDS against each of them, and the few that lie within the radius (a
 // ballot) are added to the point's sums one after the other in ascending index - the order the
 // sums had with one lane per point, so the responses are the same floats, but a 16k-point cloud is
-// 1,024 workgroups instead of 64.  The sums of a point are wave-uniform values.
+// 1,024 workgroups instead of 64.  The seven sums of a point sit in seven lanes (lane 0: n_x n_x,
+// 1: n_y n_x, 2: n_z n_x, 3: n_x n_y, 4: n_y n_y, 5: n_z n_y, 6: n_z n_z), each lane reading its two
+// factors of a neighbour's normal from LDS: a neighbour costs one multiplication and one addition.
 static constexpr int HR_PW = 4;
 __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __restrict__ xyz,
                                                               const float4* __restrict__ nrm,
@@ -35,14 +37,16 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i0 = (blockIdx.x * 4 + wave) * HR_PW;  // this wave's points: i0 .. i0 + HR_PW - 1
   float px[HR_PW], py[HR_PW], pz[HR_PW];
-  float xx[HR_PW], xy[HR_PW], xz[HR_PW], yx[HR_PW], yy[HR_PW], yz[HR_PW], zz[HR_PW];
+  float sum[HR_PW];  // lane L < 7: sum L of the point
   unsigned count[HR_PW];
+  // the planes of the tile (3: n_x, 4: n_y, 5: n_z) this lane's factors come from
+  const int plane_a = 3 + (lane < 6 ? lane % 3 : 2), plane_b = 3 + (lane < 3 ? 0 : lane < 6 ? 1 : 2);
 #pragma unroll
   for (int q = 0; q < HR_PW; ++q) {
     float4 p = make_float4(__builtin_nanf(""), 0, 0, 0);
     if (i0 + q < n) p = xyz[i0 + q];
     px[q] = p.x, py[q] = p.y, pz[q] = p.z;
-    xx[q] = xy[q] = xz[q] = yx[q] = yy[q] = yz[q] = zz[q] = 0.f;
+    sum[q] = 0.f;
     count[q] = 0;
   }
   for (int base = 0; base < n; base += HR_TILE) {
@@ -72,15 +76,10 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
         while (m) {  // wave-uniform: the neighbours among these 64, ascending
           const int j = c + __builtin_ctzll(m);
           m &= m - 1;
-          const float mx = tile[3 * HR_TILE + j], my = tile[4 * HR_TILE + j], mz = tile[5 * HR_TILE + j];
-          if (!isfinite(mx)) continue;
-          xx[q] += mx * mx;
-          xy[q] += my * mx;
-          xz[q] += mz * mx;
-          yx[q] += mx * my;
-          yy[q] += my * my;
-          yz[q] += mz * my;
-          zz[q] += mz * mz;
+          const float fa = tile[plane_a * HR_TILE + j], fb = tile[plane_b * HR_TILE + j];
+          // lane 0's first factor is n_x
+          if (!isfinite(__uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fa))))) continue;
+          sum[q] += fa * fb;
           ++count[q];
         }
       }
@@ -91,7 +90,10 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
     const int i = i0 + q;
     if (i >= n) break;
     float r = 0.f;
-    float sxx = xx[q], sxy = xy[q], sxz = xz[q], syy = yy[q], syz = yz[q], szz = zz[q];
+    auto of_lane = [&](int l) {
+      return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(sum[q]), l));
+    };
+    float sxx = of_lane(0), sxy = of_lane(1), sxz = of_lane(2), syy = of_lane(4), syz = of_lane(5), szz = of_lane(6);
     if (isfinite(px[q]) && isfinite(py[q]) && isfinite(pz[q])) {
       if (count[q] > 0) {
         const float cf = (float)count[q];
