@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LGICP_ABI_VERSION 1
+#define LGICP_ABI_VERSION 2
 
 /* call-level error codes */
 enum {
@@ -50,6 +50,18 @@ enum {
 };
 /* IcpLoopComputation::IcpCovarianceMethod (IcpLoopComputation.h:144) */
 enum { LGICP_COV_POINT2POINT = 0, LGICP_COV_POINT2PLANE = 1 };
+
+/* Inner solver of an outer GICP iteration, the part of estimateRigidTransformationBFGS
+ * (lamp_utils/include/lamp_utils/gicp.hpp:217-287).
+ * GAUSS_NEWTON: the objective of one outer iteration is reduced to a quadratic form in one pass
+ *   over the correspondences and minimised exactly on the 6 Euler parameters; the fastest, and
+ *   its answer does not move with the rounding noise of the objective.
+ * BFGS: the reference's own optimiser (pcl::BFGS with the parameters of gicp.hpp:250-258, at most
+ *   optimizer_iterations steps, gradient tolerance 1e-2) on the reference's own objective, every
+ *   function evaluation a pass over the correspondences with T * p rounded to float as in
+ *   gicp.hpp:307-310.  It stops where the reference stops, also where that is not the minimum
+ *   (few outer iterations, NoProgress inside the float noise); several times slower. */
+enum { LGICP_SOLVER_GAUSS_NEWTON = 0, LGICP_SOLVER_BFGS = 1 };
 
 /* per-pair outcome: one value per `return false` of PerformAlignment */
 enum {
@@ -103,6 +115,7 @@ typedef struct lgicp_config {
   int harris_response;
   /* device-side knobs with no counterpart in the reference */
   size_t workspace_bytes;     /* upper bound for per-batch device scratch (0 = 16 GiB) */
+  int solver;                 /* LGICP_SOLVER_* (0 = Gauss-Newton) */
   int reserved[8];            /* tuning/diagnostics, 0 = default: [0] queries per lane of the
                                  exhaustive 1-NN kernel (2, 4, 8); [1] its target splits;
                                  [2] 1 = use the exhaustive 1-NN kernel instead of the pruned

@@ -78,6 +78,12 @@ struct Arena {
   }
 };
 
+// per-pair device scratch of a batch: transformed source, packed matches, certificates (+ the
+// BFGS back end's records, 72 bytes per source point)
+inline size_t pair_scratch_bytes(const lgicp_config& cfg, int n_src) {
+  return (size_t)n_src * (cfg.solver == LGICP_SOLVER_BFGS ? 40 + 72 : 40) + 1536;
+}
+
 struct CloudPlan {  // one distinct point cloud of a batch
   uint64_t key;
   bool accumulated;
@@ -232,6 +238,8 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
     return fail(nullptr, LGICP_E_HIP, "hipGetDeviceProperties failed");
+  if (cfg->solver != LGICP_SOLVER_GAUSS_NEWTON && cfg->solver != LGICP_SOLVER_BFGS)
+    return fail(nullptr, LGICP_E_INVALID, "solver %d is not one of LGICP_SOLVER_*", cfg->solver);
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(nullptr, LGICP_E_NO_DEVICE, "device %d is %s, this library is built for gfx950",
                 cfg->device, prop.gcnArchName);
@@ -1030,7 +1038,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
 
   // ---- device scratch ----------------------------------------------------------------------
   size_t pair_bytes = 0;
-  for (auto& p : bp.pairs) pair_bytes += (size_t)bp.clouds[p.src_cloud].n * 40 + 768;
+  for (auto& p : bp.pairs) pair_bytes += pair_scratch_bytes(ctx->cfg, bp.clouds[p.src_cloud].n);
   HIP_TRY(ctx, W->arena.reserve(bp.bytes + pair_bytes + 4096));
   Arena ar{W};
 
@@ -1062,6 +1070,11 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     pd.keys = ar.take<nnkey_t>((size_t)pd.n_src);
     // reserved[6] = 2: seeds but no certificates (diagnostics)
     pd.cert = (ctx->nn_exhaustive || cfg.reserved[6] == 2) ? nullptr : ar.take<float4>((size_t)pd.n_src);
+    if (cfg.solver == LGICP_SOLVER_BFGS) {
+      pd.bf_a = ar.take<float4>((size_t)pd.n_src);
+      pd.bf_b = ar.take<float2>((size_t)pd.n_src);
+      pd.bf_m = ar.take<double2>((size_t)pd.n_src * 3);
+    }
     std::memcpy(pd.guess, pp.guess, sizeof(pd.guess));
     max_src_n = std::max(max_src_n, pd.n_src);
     PairState& s = h_state[p];
@@ -1337,12 +1350,21 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     HIP_TRY(ctx, hipEventRecord(a, st));
     HIP_TRY(ctx, nn_pass(false));
     HIP_TRY(ctx, hipEventRecord(b, st));
-    HIP_TRY(ctx, launch_gicp_reduce(d_clouds, d_pairs, d_state,
-                                    d_bmap_red, (int)h_bmap_red.size(), sp.corr_dist2,
-                                    W->d_partials.p, !cfg.covariance_from_knn, st));
-    HIP_TRY(ctx, hipEventRecord(c, st));
-    HIP_TRY(ctx, launch_gicp_solve(d_pairs, d_state, n_pairs, d_ints,
-                                   W->d_partials.p, sp, d_done, st));
+    if (cfg.solver == LGICP_SOLVER_BFGS) {
+      HIP_TRY(ctx, launch_bfgs_prepare(d_clouds, d_pairs, d_state,
+                                       d_bmap_red, (int)h_bmap_red.size(), sp.corr_dist2,
+                                       W->d_partials.p, !cfg.covariance_from_knn, st));
+      HIP_TRY(ctx, hipEventRecord(c, st));
+      HIP_TRY(ctx, launch_gicp_bfgs(d_pairs, d_state, n_pairs, d_ints,
+                                    W->d_partials.p, sp, d_done, st));
+    } else {
+      HIP_TRY(ctx, launch_gicp_reduce(d_clouds, d_pairs, d_state,
+                                      d_bmap_red, (int)h_bmap_red.size(), sp.corr_dist2,
+                                      W->d_partials.p, !cfg.covariance_from_knn, st));
+      HIP_TRY(ctx, hipEventRecord(c, st));
+      HIP_TRY(ctx, launch_gicp_solve(d_pairs, d_state, n_pairs, d_ints,
+                                     W->d_partials.p, sp, d_done, st));
+    }
     HIP_TRY(ctx, hipEventRecord(d, st));
     // once this event has passed, every flag of this iteration is visible to the host (a
     // later solve kernel that is already running can only add flags, never take one back)
@@ -1669,7 +1691,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
         default:
           for (int k = 0; k < 16; ++k) pp.guess[k] = (k % 5 == 0) ? 1.f : 0.f;
       }
-      pair_bytes += (size_t)bp.clouds[pp.src_cloud].n * 40 + 768;
+      pair_bytes += pair_scratch_bytes(cfg, bp.clouds[pp.src_cloud].n);
       bp.pairs.push_back(pp);
     }
     if (!bp.pairs.empty()) plans.push_back(std::move(bp));

@@ -107,6 +107,10 @@ struct PairDev {
   nnkey_t* keys;    // n_src packed 1-NN results
   float4* cert;     // optional, n_src: where each query stood at its last full lookup (x, y, z) and
                     // a lower bound (w) of its distance from there to every target but its match
+  // BFGS back end only: one record per source point and outer iteration (gicp_bfgs.hip)
+  float4* bf_a;     // guess * source (x, y, z), matched target x
+  float2* bf_b;     // matched target y, z
+  double2* bf_m;    // 3 per point: M00 M01 | M02 M11 | M12 M22; all zero without a correspondence
   float guess[16];
   int n_src;
   int n_tgt;
@@ -213,6 +217,15 @@ hipError_t launch_gicp_reduce(const CloudDev* clouds, const PairDev* pairs, cons
 hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
                              const int* n_chunks, const double* partials, SolveParams sp,
                              int* n_done, hipStream_t stream);
+// BFGS back end (gicp_bfgs.hip): records + correspondence counts of one outer iteration (same block
+// map as launch_gicp_reduce; counts land in partials[(pair, chunk)][0]), then the inner solve,
+// applyState and the convergence test, one workgroup per pair
+hipError_t launch_bfgs_prepare(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
+                               const int4* bmap, int n_blocks, double corr_dist2, double* partials,
+                               bool compact, hipStream_t stream);
+hipError_t launch_gicp_bfgs(const PairDev* pairs, PairState* st, int n_pairs, const int* n_chunks,
+                            const double* partials, SolveParams sp, int* n_done,
+                            hipStream_t stream);
 hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
                               const int4* bmap, int n_blocks, double* partials, bool point2point,
                               hipStream_t stream);

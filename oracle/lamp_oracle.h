@@ -86,6 +86,11 @@ typedef struct lo_gicp_params {
   int gn_cycle_exit;         /* 1 (default): the Gauss-Newton back end's limit-cycle exit; 0: off */
   int residual_double;       /* 0 (default, the reference): BFGS functor rounds T*p to float
                                 (gicp.hpp:307-310); 1: residual in double from the float matrix */
+  int sum_order;             /* 0 (default, the reference): the functor adds the correspondences one
+                                after the other (gicp.hpp:298-315); 1: the order of a 512-lane
+                                parallel sum (lane = source index mod 512, a butterfly over each
+                                group of 64 lanes, the 8 groups in turn) -- what a different but
+                                equally valid order of the same additions does to the answer */
 } lo_gicp_params;
 
 void lo_gicp_default_params(lo_gicp_params* p);

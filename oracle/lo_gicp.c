@@ -166,6 +166,7 @@ typedef struct {
   const double* mahal; /* [n_src][9] */
   long n_evals;
   int residual_double; /* measurement knob: 1 = T*p in double instead of the reference's float */
+  int sum_order;       /* measurement knob: 1 = the sums in the order of a 512-lane parallel sum */
 } lo_functor;
 
 /* applyState (gicp.hpp:619-634) on t = identity:
@@ -261,41 +262,69 @@ static void r_derivative(const double x[6], const double R[9], double g[6]) {
 
 /* OptimizationFunctorWithIndices::fdf / operator() / df (gicp.hpp:290-402).
  * base_transformation_ is the identity throughout (gicp.hpp:435). */
+/* per-correspondence terms: res^T M res, M res, p (M res)^T */
+static inline void functor_terms(const lo_functor* F, const float T[16], int i, double t[13]) {
+  const float* ps = F->src + 3 * F->si[i];
+  const float* pt = F->tgt + 3 * F->ti[i];
+  float pp[3];
+  xform4(T, ps, pp);
+  double res[3] = {(double)(pp[0] - pt[0]), (double)(pp[1] - pt[1]), (double)(pp[2] - pt[2])};
+  if (F->residual_double)
+    for (int a = 0; a < 3; ++a)
+      res[a] = ((double)T[a * 4] * (double)ps[0] + (double)T[a * 4 + 1] * (double)ps[1] +
+                (double)T[a * 4 + 2] * (double)ps[2] + (double)T[a * 4 + 3]) -
+               (double)pt[a];
+  const double* M = F->mahal + 9 * (size_t)F->si[i];
+  const double temp[3] = {M[0] * res[0] + M[1] * res[1] + M[2] * res[2],
+                          M[3] * res[0] + M[4] * res[1] + M[5] * res[2],
+                          M[6] * res[0] + M[7] * res[1] + M[8] * res[2]};
+  t[0] = res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2];
+  t[1] = temp[0];
+  t[2] = temp[1];
+  t[3] = temp[2];
+  /* pp = base_transformation_ * p_src = p_src ; R += p_src3 * temp^T */
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) t[4 + a * 3 + b] = (double)ps[a] * temp[b];
+}
+
 static void functor_fdf(lo_functor* F, const double x[6], double* f_out, double* g /*nullable*/) {
   float T[16];
   lo_apply_state(x, T);
-  double f = 0.0, gt[3] = {0, 0, 0}, Racc[9] = {0};
-  for (int i = 0; i < F->m; ++i) {
-    const float* ps = F->src + 3 * F->si[i];
-    const float* pt = F->tgt + 3 * F->ti[i];
-    float pp[3];
-    xform4(T, ps, pp);
-    double res[3] = {(double)(pp[0] - pt[0]), (double)(pp[1] - pt[1]), (double)(pp[2] - pt[2])};
-    if (F->residual_double)
-      for (int a = 0; a < 3; ++a)
-        res[a] = ((double)T[a * 4] * (double)ps[0] + (double)T[a * 4 + 1] * (double)ps[1] +
-                  (double)T[a * 4 + 2] * (double)ps[2] + (double)T[a * 4 + 3]) -
-                 (double)pt[a];
-    const double* M = F->mahal + 9 * (size_t)F->si[i];
-    const double temp[3] = {M[0] * res[0] + M[1] * res[1] + M[2] * res[2],
-                            M[3] * res[0] + M[4] * res[1] + M[5] * res[2],
-                            M[6] * res[0] + M[7] * res[1] + M[8] * res[2]};
-    f += res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2];
-    if (g) {
-      gt[0] += temp[0];
-      gt[1] += temp[1];
-      gt[2] += temp[2];
-      /* pp = base_transformation_ * p_src = p_src ; R += p_src3 * temp^T */
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) Racc[a * 3 + b] += (double)ps[a] * temp[b];
+  double tot[13] = {0};
+  if (!F->sum_order) {
+    /* the reference: one running sum per quantity, correspondences in order */
+    for (int i = 0; i < F->m; ++i) {
+      double t[13];
+      functor_terms(F, T, i, t);
+      tot[0] += t[0];
+      if (g)
+        for (int c = 1; c < 13; ++c) tot[c] += t[c];
+    }
+  } else {
+    /* measurement knob: the same additions in the order of a 512-lane parallel sum */
+    enum { LANES = 512, GROUP = 64 };
+    double P[LANES][13];
+    memset(P, 0, sizeof(P));
+    for (int i = 0; i < F->m; ++i) {
+      double t[13];
+      functor_terms(F, T, i, t);
+      double* A = P[F->si[i] % LANES];
+      for (int c = 0; c < 13; ++c) A[c] += t[c];
+    }
+    for (int g0 = 0; g0 < LANES; g0 += GROUP) {
+      for (int off = GROUP / 2; off >= 1; off /= 2)
+        for (int l = 0; l < off; ++l)
+          for (int c = 0; c < 13; ++c) P[g0 + l][c] += P[g0 + l + off][c];
+      for (int c = 0; c < 13; ++c) tot[c] += P[g0][c];
     }
   }
   F->n_evals++;
   const double m = (double)F->m;
-  if (f_out) *f_out = f / m;
+  if (f_out) *f_out = tot[0] / m;
   if (g) {
-    for (int a = 0; a < 3; ++a) g[a] = gt[a] * (2.0 / m);
-    for (int a = 0; a < 9; ++a) Racc[a] *= 2.0 / m;
+    double Racc[9];
+    for (int a = 0; a < 3; ++a) g[a] = tot[1 + a] * (2.0 / m);
+    for (int a = 0; a < 9; ++a) Racc[a] = tot[4 + a] * (2.0 / m);
     r_derivative(x, Racc, g);
   }
 }
@@ -303,7 +332,7 @@ static void functor_fdf(lo_functor* F, const double x[6], double* f_out, double*
 void lo_gicp_cost_grad(const float* src_xyz_guess, const float* tgt_xyz, const int32_t* src_idx,
                        const int32_t* tgt_idx, int m, const double* mahal9, const double x[6],
                        double* f, double g[6]) {
-  lo_functor F = {src_xyz_guess, tgt_xyz, src_idx, tgt_idx, m, mahal9, 0, 0};
+  lo_functor F = {src_xyz_guess, tgt_xyz, src_idx, tgt_idx, m, mahal9, 0, 0, 0};
   functor_fdf(&F, x, f, g);
 }
 
@@ -907,6 +936,7 @@ void lo_gicp_default_params(lo_gicp_params* p) {
   p->gradient_tol = 1e-2;          /* gicp.hpp:250 */
   p->gn_cycle_exit = 1;
   p->residual_double = 0;
+  p->sum_order = 0;
 }
 
 int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* src_normals,
@@ -1000,7 +1030,7 @@ int lo_gicp_align(const lo_gicp_params* p, const float* src_xyz, const float* sr
       memcpy(trace_T + 16 * (size_t)nr_iterations, T, sizeof(float) * 16);
     out->last_num_correspondences = m;
     memcpy(Tprev, T, sizeof(T)); /* previous_transformation_ = transformation_ */
-    lo_functor F = {output, tgt_xyz, si, ti, m, mahal, 0, p->residual_double};
+    lo_functor F = {output, tgt_xyz, si, ti, m, mahal, 0, p->residual_double, p->sum_order};
     const int rc = (p->solver == LO_SOLVER_GN)
                        ? estimate_gn(&F, p->max_inner_iterations, T)
                        : estimate_bfgs(&F, p->max_inner_iterations,
@@ -1106,7 +1136,7 @@ int lo_gicp_objective_at(const lo_gicp_params* p, const float* src_xyz, const fl
   }
   int rc = -1;
   if (m >= 4) {
-    lo_functor F = {output, tgt_xyz, si, ti, m, mahal, 0, 1};
+    lo_functor F = {output, tgt_xyz, si, ti, m, mahal, 0, 1, 0};
     const double x0[6] = {0, 0, 0, 0, 0, 0};
     functor_fdf(&F, x0, f, g);
     rc = 0;

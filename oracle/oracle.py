@@ -31,7 +31,7 @@ class GicpParams(C.Structure):
                 ("max_inner_iterations", C.c_int), ("k_correspondences", C.c_int),
                 ("gicp_epsilon", C.c_double), ("cov_from_knn", C.c_int), ("solver", C.c_int),
                 ("use_kdtree", C.c_int), ("threads", C.c_int), ("gradient_tol", C.c_double),
-                ("gn_cycle_exit", C.c_int), ("residual_double", C.c_int)]
+                ("gn_cycle_exit", C.c_int), ("residual_double", C.c_int), ("sum_order", C.c_int)]
 
 
 class GicpResult(C.Structure):
