@@ -3,6 +3,7 @@
 // reference's float objective).
 #pragma once
 
+#include "host_sincosf.h"
 #include "lgicp_device.h"
 
 namespace lgicp {
@@ -50,15 +51,14 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 // applyState on the identity (gicp.hpp:619-634): Eigen multiplies the three AngleAxisf as
 // float quaternions and converts the product to a rotation matrix
-// ROUNDED: the float sine and cosine are the correctly rounded ones (computed in double and
-// rounded once), which is what a host libm returns for all but a fraction of a percent of its
-// arguments; the device's own sinf / cosf differ from it in the last bit far more often, and the
-// BFGS back end is compared with a host run evaluation by evaluation.
-template <bool ROUNDED = false>
+// HOST_LIBM: the float sine and cosine are the host libm's (host_sincosf.h) instead of the
+// device's own, which differ from it in the last bit for a few arguments in a thousand: the BFGS
+// back end is compared with a host run evaluation by evaluation.
+template <bool HOST_LIBM = false>
 static __device__ void apply_state(const double x[6], float T[16]) {
   const float az = (float)x[5], ay = (float)x[4], ax = (float)x[3];
-  auto hc = [](float h) { return ROUNDED ? (float)cos((double)h) : cosf(h); };
-  auto hs = [](float h) { return ROUNDED ? (float)sin((double)h) : sinf(h); };
+  auto hc = [](float h) { return HOST_LIBM ? host_cosf(h) : cosf(h); };
+  auto hs = [](float h) { return HOST_LIBM ? host_sinf(h) : sinf(h); };
   const float qz[4] = {hc(0.5f * az), 0.f, 0.f, hs(0.5f * az)};
   const float qy[4] = {hc(0.5f * ay), 0.f, hs(0.5f * ay), 0.f};
   const float qx[4] = {hc(0.5f * ax), hs(0.5f * ax), 0.f, 0.f};

@@ -131,43 +131,131 @@ def measure(case, threads=8, self_gap=True):
     return out
 
 
+# The reference's two parameter blocks (loop_closure/config/laser_parameters.yaml:5-147 robot,
+# :153-301 base station) as far as the GICP loop sees them
+BLOCKS = {"base": dict(corr_dist=0.5, max_iterations=200),
+          "robot": dict(corr_dist=0.1, max_iterations=5)}
+
+
+def measure_bfgs(case, block, threads=8):
+    """The engine's BFGS back end (lgicp_config.solver = LGICP_SOLVER_BFGS) against the oracle's
+    BFGS, i.e. the reference's solver, under the reference's base-station or robot block, from an
+    identity guess.  The oracle runs twice: with the functor's sums in the reference's serial
+    order, and with the same additions in the order of a 512-lane parallel sum (the order the
+    device uses) -- the gap between those two CPU runs is what the reference's answer owes to the
+    order of its additions alone.  The Gauss-Newton back end is measured beside it."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    c = CASES[case]
+    work = Workload(c["config"], pairs=c["pairs"], points=c["points"], keyframes=c["keyframes"])
+    base = block == "base"
+    gpu = {}
+    for name, solver in (("gn", capi.SOLVER_GAUSS_NEWTON), ("bfgs", capi.SOLVER_BFGS)):
+        # gates wide open: what is compared is the alignment, not the verdict on it
+        cfg = capi.default_config(base, init_method=capi.INIT_IDENTITY, solver=solver,
+                                  accumulate_source=0, transform_thresholding=0,
+                                  max_tolerable_fitness=1e9)
+        ctx = capi.Context(cfg)
+        try:
+            work.register(ctx)
+            gpu[name] = [capi.result_to_dict(r) for r in ctx.submit(work.candidates())]
+        finally:
+            ctx.close()
+    P = {order: O.base_gicp_params(solver=O.SOLVER_BFGS, sum_order=order, **BLOCKS[block])
+         for order in (0, 1)}
+
+    def cpu_one(i):
+        a, b = work.pairs[i]
+        src, sn = work.keyframes[a]
+        tgt, tn = work.keyframes[b]
+        return [O.gicp_align(P[order], src, sn, tgt, tn, np.eye(4)) for order in (0, 1)]
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        cpu = list(ex.map(cpu_one, range(len(work.pairs))))
+    serial = [c_[0] for c_ in cpu]
+    parallel = [c_[1] for c_ in cpu]
+
+    def gap(ref, res, key):
+        g = [O.pose_gap(r["T"], d[key]) for r, d in zip(ref, res)]
+        same = sum(np.array_equal(r["T"], np.asarray(d[key], np.float32).reshape(4, 4))
+                   for r, d in zip(ref, res))
+        return {"rot_rad": _dist([x[0] for x in g]), "trans_m": _dist([x[1] for x in g]),
+                "bit_identical": int(same), "pairs": len(res)}
+
+    return {
+        "case": case, "block": block, "workload": c, "seed": work.seed, "pairs": len(work.pairs),
+        "gpu_bfgs_vs_oracle_bfgs": gap(serial, gpu["bfgs"], "T_icp"),
+        "gpu_bfgs_vs_oracle_bfgs_parallel_sum_order": gap(parallel, gpu["bfgs"], "T_icp"),
+        "oracle_bfgs_parallel_sum_order_vs_serial": gap(serial, parallel, "T"),
+        "gpu_gn_vs_oracle_bfgs": gap(serial, gpu["gn"], "T_icp"),
+        "outer_iterations_mean": {"gpu_bfgs": float(np.mean([r["iterations"] for r in gpu["bfgs"]])),
+                                  "gpu_gn": float(np.mean([r["iterations"] for r in gpu["gn"]])),
+                                  "oracle_bfgs": float(np.mean([r["iterations"] for r in serial]))},
+        "equal_iteration_counts_gpu_bfgs_oracle": int(sum(
+            r["iterations"] == d["iterations"] for r, d in zip(serial, gpu["bfgs"]))),
+    }
+
+
 def _golden():
     return {c["case"]: c for c in json.load(open(GOLDEN))["cases"]}
 
 
-@pytest.mark.parametrize("case", ["C1", "C2"])
-def test_gpu_vs_reference_solver_within_the_reference_own_noise(case):
-    """The bound that holds against the reference's solver.  north_star asks for 1e-4 rad /
-    1e-4 m: nine pairs in ten meet the rotation bar and the median pair the translation bar;
-    the tails (rotation up to 2e-4 rad, translation up to 6e-4 m over 128 measured pairs) are
-    the size of the reference's own self-gap (its answer moves by up to a millimetre when the
-    guess moves by a micrometre), so no tighter bound on the maximum can hold against it."""
-    g = _golden()[case]
-    m = measure(case)
-    d = m["gpu_vs_bfgs"]
-    assert d["rot_rad"]["p90"] < 1e-4 and d["rot_rad"]["max"] < 5e-4, d
-    assert d["trans_m"]["p50"] < 1e-4 and d["trans_m"]["max"] < 1e-3, d
-    # the gap is not larger than what the reference does to itself under a 1 um change of guess
-    bs = m["bfgs_self_gap_guess_moved_1um"]
-    assert d["trans_m"]["p50"] <= 3.0 * max(bs["trans_m"]["p50"], 2e-5), (d, bs)
-    assert d["trans_m"]["max"] <= 3.0 * max(bs["trans_m"]["max"], 1e-4), (d, bs)
-    assert d["rot_rad"]["max"] <= 3.0 * max(bs["rot_rad"]["max"], 2e-5), (d, bs)
-    # while the GPU's own answer is stable under the same change
-    gs = m["gpu_self_gap_guess_moved_1um"]
-    assert gs["trans_m"]["p50"] < 1e-6 and gs["trans_m"]["max"] < 1e-4, gs
-    assert gs["rot_rad"]["p50"] < 1e-7 and gs["rot_rad"]["max"] < 1e-4, gs
-    # both minimise the same objective: equal values, and the GPU's answer is the more stationary
-    s = m["stationarity_grad_norm"]
-    assert s["gpu"]["p50"] < 0.1 * s["bfgs"]["p50"], s
-    assert s["gpu"]["max"] < 1e-2, s   # the reference's own gradient tolerance (gicp.hpp:250)
-    assert m["objective_rel_diff_gpu_minus_bfgs"]["max"] < 5e-3, m["objective_rel_diff_gpu_minus_bfgs"]
-    # the limit-cycle exit moves a pose by far less than the reference's noise
-    cyc = m["cycle_exit"]["pose_change_without_it"]
-    if cyc is not None:
-        assert cyc["trans_m"]["max"] < 2e-5 and cyc["rot_rad"]["max"] < 1e-5, cyc
-    # the committed distribution is what this measurement reproduces (same seeds, same code)
-    assert d["trans_m"]["max"] <= 2.0 * g["gpu_vs_bfgs"]["trans_m"]["max"] + 1e-5
-    assert d["rot_rad"]["max"] <= 2.0 * g["gpu_vs_bfgs"]["rot_rad"]["max"] + 1e-6
+def _golden_bfgs():
+    return {(c["case"], c["block"]): c for c in json.load(open(GOLDEN))["bfgs_back_end"]}
+
+
+@pytest.mark.parametrize("block", ["base", "robot"])
+@pytest.mark.parametrize("case", ["C1", "C2", "C3"])
+def test_bfgs_back_end_follows_the_reference_solver(case, block):
+    """north_star's 1e-4 rad / 1e-4 m against the reference's solver, with the back end that runs
+    that solver.  Against the oracle whose sums run in the device's order the float matrices are
+    the same bits for (nearly) every pair of the base-station block and for most of the robot
+    block's.  Against the oracle in the reference's serial order three pairs in four still agree
+    to the bit; the others differ by what that oracle's own answer moves when nothing but the
+    order of its additions changes (the two CPU runs measured here: same counts, same
+    distributions), which at the base station's fixed point stays under the bar at p90 and in the
+    robot block's five cut-short iterations from an identity guess does not -- for the reference
+    itself."""
+    m = measure_bfgs(case, block)
+    n = m["pairs"]
+    par = m["gpu_bfgs_vs_oracle_bfgs_parallel_sum_order"]
+    ser = m["gpu_bfgs_vs_oracle_bfgs"]
+    floor = m["oracle_bfgs_parallel_sum_order_vs_serial"]
+    # same additions in the same order: the same float matrices
+    assert par["rot_rad"]["p50"] < 1e-9 and par["trans_m"]["p50"] < 1e-9, par
+    assert par["bit_identical"] >= (0.9 if block == "base" else 0.7) * n, par
+    if block == "base":
+        assert par["rot_rad"]["p90"] < 1e-9 and par["trans_m"]["p90"] < 1e-9, par
+        assert par["rot_rad"]["max"] < 1e-4 and par["trans_m"]["max"] < 2e-4, par
+    # the reference's order of additions: as close to it as the oracle in the device's order is
+    assert ser["rot_rad"]["p50"] < 1e-9 and ser["trans_m"]["p50"] < 1e-9, ser
+    assert ser["bit_identical"] >= floor["bit_identical"] - 3, (ser, floor)
+    if block == "base":
+        assert ser["rot_rad"]["p90"] < 1e-4 and ser["trans_m"]["p90"] < 1e-4, ser
+    for k in ("rot_rad", "trans_m"):
+        assert ser[k]["p90"] <= 3.0 * max(floor[k]["p90"], 3e-5), (k, ser, floor)
+        assert ser[k]["max"] <= 3.0 * max(floor[k]["max"], 1e-4), (k, ser, floor)
+    # where the loop is cut short Gauss-Newton is far from the reference's solver, this is not
+    gn = m["gpu_gn_vs_oracle_bfgs"]
+    if block == "robot":
+        assert ser["trans_m"]["p90"] < 0.5 * gn["trans_m"]["p90"], (ser, gn)
+    # the committed distribution is what this measurement reproduces
+    g = _golden_bfgs()[(case, block)]
+    assert abs(ser["bit_identical"] - g["gpu_bfgs_vs_oracle_bfgs"]["bit_identical"]) <= 4
+    assert abs(par["bit_identical"] - g["gpu_bfgs_vs_oracle_bfgs_parallel_sum_order"]["bit_identical"]) <= 4
+
+
+def test_committed_bfgs_distribution_covers_both_blocks():
+    g = _golden_bfgs()
+    assert sorted(g) == sorted((c, b) for c in ("C1", "C2", "C3", "C5") for b in ("base", "robot"))
+    for (case, block), m in g.items():
+        assert m["pairs"] >= 32
+        par = m["gpu_bfgs_vs_oracle_bfgs_parallel_sum_order"]
+        assert par["rot_rad"]["p50"] < 1e-9 and par["trans_m"]["p50"] < 1e-9, (case, block, par)
+        if block == "base":
+            assert par["rot_rad"]["p90"] < 1e-9 and par["trans_m"]["p90"] < 1e-9, (case, par)
+            ser = m["gpu_bfgs_vs_oracle_bfgs"]
+            assert ser["rot_rad"]["p90"] < 1e-4 and ser["trans_m"]["p90"] < 1e-4, (case, ser)
 
 
 def test_committed_gap_distribution_covers_every_configuration():
