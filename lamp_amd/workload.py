@@ -138,12 +138,16 @@ class Workload:
     (key_from, key_to); truth: (key_from, key_to) -> 4x4 source->target transform"""
 
     def __init__(self, config="C2", pairs=None, points=None, keyframes=None, shard=0,
-                 pose_noise=(0.0, 0.0), key_offset=0, frame_offset=None, progress=None):
+                 pose_noise=(0.0, 0.0), key_offset=0, frame_offset=None, progress=None,
+                 consecutive_keys=False):
         """shard: changes the seed (another batch of the same shape); key_offset: added to every
         key, so that several workloads can live in one engine context; frame_offset: (max rotation
         in deg, max translation in m) of every keyframe's frame against its registered pose
         (default: C4 (45, 2.5), other configurations none); progress: called with a line of text
-        every 64 keyframes (large configurations take minutes to generate)."""
+        every 64 keyframes (large configurations take minutes to generate); consecutive_keys: the
+        keyframes of one place get consecutive keys, as along a robot's trajectory, so that the
+        reference's AccumulateScans (IcpLoopComputation.cc:910-947) finds key +- 1, +- 2 and a
+        target grows to up to five scans (default: keys 10 apart, nothing is accumulated)."""
         c = dict(CONFIGS[config])
         if pairs is not None:
             c["pairs"] = pairs
@@ -174,8 +178,9 @@ class Workload:
                 R = base_R @ _rot(axis, np.deg2rad(rng.uniform(0, 2.5)))
                 d = rng.standard_normal(3)
                 t = base_t + d / np.linalg.norm(d) * rng.uniform(0, 0.25)
-                # keys are spaced by 10 so that no neighbour scan gets accumulated
-                k = 1000 + 10 * key + key_offset
+                # keys are spaced by 10 so that no neighbour scan gets accumulated, or consecutive
+                # within a place with a gap between places
+                k = (1000 + key + 10 * pl if consecutive_keys else 1000 + 10 * key) + key_offset
                 key += 1
                 pts, nrms = make_keyframe(place, R, t, self.n_points, rng)
                 Rs, ts = R, t                      # the sensor's pose = what odometry reports
