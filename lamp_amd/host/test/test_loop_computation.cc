@@ -108,7 +108,8 @@ static void OnDevice() {
   ParameterServer ps = ParameterServer::ReferenceDefaults();
   ps.Set("base/icp_initialization_method", LGICP_INIT_ODOMETRY);
   NodeHandle nh{"base", &ps};
-  {  // TestLoopComputation.PerformAlignment
+  {  // TestLoopComputation.PerformAlignment with the initialisation switched to ODOMETRY (the
+     // reference's own configuration, FEATURES -> SAC-IA -> GICP, is the next block)
     Probe icp;
     CHECK(icp.Initialize(nh));
     PointCloud corner = Corner(), moved = Shift(corner, 1.f, -0.001f);
@@ -132,7 +133,10 @@ static void OnDevice() {
     std::printf("{\"perform_alignment_t\": [%.6f, %.6f, %.6f], \"fitness\": %.3g, ",
                 tf.translation[0], tf.translation[1], tf.translation[2], fit);
   }
-  {  // TestLoopComputation.TestSacInitialAlign and PerformAlignment with the default FEATURES init
+  {  // TestLoopComputation.TestSacInitialAlign (test_loop_computation.cc:78-99) and
+     // TestLoopComputation.PerformAlignment exactly as the reference runs it
+     // (test_loop_computation.cc:125-182): the base block untouched, i.e. FEATURES initialisation
+     // (SAC-IA from Harris keypoints and FPFH descriptors), POINT2PLANE covariance, 200 iterations
     ParameterServer def = ParameterServer::ReferenceDefaults();
     NodeHandle nhd{"base", &def};
     Probe icp;
@@ -162,9 +166,13 @@ static void OnDevice() {
     icp.KeyedPoseCallback(kp);
     Transform3 tf;
     double cov[36], fit = -1;
+    CHECK(icp.config().init_method == LGICP_INIT_FEATURES && icp.config().iterations == 200);
     CHECK(icp.PerformAlignment(100, 0, kp100.pose, kp0.pose, &tf, cov, &fit));
     CHECK(std::fabs(tf.translation[0] - 1) < 1e-3 && std::fabs(tf.translation[1] + 0.001) < 1e-3 &&
           std::fabs(tf.translation[2]) < 1e-3);
+    for (int i = 0; i < 9; ++i) CHECK(std::fabs(tf.rotation[i] - (i % 4 == 0 ? 1 : 0)) < 1e-3);
+    std::printf("\"perform_alignment_reference_defaults_t\": [%.6f, %.6f, %.6f], ", tf.translation[0],
+                tf.translation[1], tf.translation[2]);
   }
   {  // TestICPComputation.TestThreadedEqualsNonThreaded, device batch instead of the pool
     ps.Set("base/icp_lc/iterations", 100);

@@ -67,6 +67,44 @@ def test_one_pair_of_each_configuration(config, points):
         assert ang < 1e-3 and te < 1e-3
 
 
+@pytest.mark.parametrize("solver", ["gn", "bfgs"])
+@pytest.mark.parametrize("config", ["C1", "C2"])
+def test_one_pair_of_each_configuration_with_knn_covariances(config, solver):
+    """The covariance branch north_star's kernel (2) names: 20 nearest neighbours in the point's
+    own cloud, SVD, singular values replaced by (1, 1, 1e-3) (gicp.hpp:83-155), instead of the
+    stored normals.  Same tolerances as above, against the oracle run with the same branch; with
+    the BFGS back end against the oracle's BFGS in the device's order of additions."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload(config, pairs=2, keyframes=2)
+    c = capi.Context(init_method=capi.INIT_IDENTITY, transform_thresholding=0, covariance_from_knn=1,
+                     solver=capi.SOLVER_BFGS if solver == "bfgs" else capi.SOLVER_GAUSS_NEWTON)
+    try:
+        work.register(c)
+        res = [capi.result_to_dict(r) for r in c.submit(work.candidates())]
+    finally:
+        c.close()
+    ident = O.pose_from_quat([1, 0, 0, 0], [0, 0, 0])
+    for d, (a, b) in zip(res, work.pairs):
+        src, sn = work.keyframes[a]
+        tgt, tn = work.keyframes[b]
+        params = O.base_icp_params(init_method=O.INIT_IDENTITY, threads=8, transform_thresholding=0,
+                                   cov_from_knn=1,
+                                   solver=O.SOLVER_BFGS if solver == "bfgs" else O.SOLVER_GN,
+                                   sum_order=1 if solver == "bfgs" else 0)
+        ref = O.perform_alignment(params, src, sn, tgt, tn, src, tn, ident)
+        assert d["status"] == ref["status"] == 0
+        ang, te = _rot_err(ref["T_icp"], d["T_icp"])
+        assert ang < 1e-4 and te < 1e-4, (config, solver, ang, te)
+        assert abs(d["fitness"] - ref["fitness"]) <= 1e-5 * ref["fitness"]
+        assert _close_per_entry(d["covariance"], ref["covariance"], 1e-4)
+        _, idx = O.fitness_score(src, tgt, d["T_icp"])
+        _, Ap = O.icp_cov_point_plane(src, tn, idx, d["T_icp"])
+        assert _close_per_entry(d["information"], Ap / 0.0025, 1e-5)
+        ang, te = _rot_err(work.truth[(a, b)], d["T_icp"])
+        assert ang < 5e-3 and te < 2e-2
+
+
 def test_batch_and_slot_independence():
     """A pair's result does not depend on what else is in the submit, on the order of the
     candidates, or on how the submit is cut over the two concurrent batch slots."""
