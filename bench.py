@@ -324,7 +324,10 @@ def main():
     from lamp_amd.workload import Workload
 
     strong = args.mode == "strong"
-    n_batches = args.batches or (4 if args.config == "C2" and not strong else 1)
+    # (C4 keeps Harris keypoints and FPFH descriptors per keyframe: two batches in rotation, so that
+    # a step does not simply meet the features its predecessor left; value_cold has none cached)
+    n_batches = args.batches or ((4 if args.config == "C2" else (2 if args.config == "C4" else 1))
+                                 if not strong else 1)
     # ---- workloads: the batches this rank owns ------------------------------------------------
     works, cand_lists, key_lists = [], [], []
     for b in range(n_batches):
@@ -398,9 +401,8 @@ def main():
 
     def collect_overlapped(n_steps, first, depth):
         """`depth` steps in flight, each lane of steps submitted by its own thread; results are
-        taken (and, with several ranks, gathered) in step order by this thread.  Stage times are what lgicp_get_stats
-        reports as "last submit" when a step returns: with submits side by side that is now and
-        then the neighbour's, so the sums are indicative; the launch and distance counters are
+        taken (and, with several ranks, gathered) in step order by this thread.  Stage times are
+        those of the step's own submit (lgicp_submit_stats); the launch and distance counters are
         exact differences over the region."""
         acc = dict(nn_ms=0.0, nn_launches=0.0, nn_evals=0.0, nn_exec=0.0, red_ms=0.0,
                    red_launches=0.0, red_points=0.0, red_inliers=0.0, cycle_exits=0.0,
@@ -411,9 +413,9 @@ def main():
         res = []
 
         def submit_step(k, i):
-            out = ctx.submit_packed(packed_sets[k][i % n_batches])
+            out, st = ctx.submit_packed_stats(packed_sets[k][i % n_batches])
             rec = pack_results(out, len(cand_lists[i % n_batches])) if dist is not None else None
-            return out, rec, ctx.stats()
+            return out, rec, st
 
         def on_result(i, value):
             out, rec, s1 = value

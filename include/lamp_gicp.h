@@ -48,6 +48,13 @@ enum {
   LGICP_INIT_TEASERPP = 4,
   LGICP_INIT_CANDIDATE = 5
 };
+/* TEASERPP: the scale-consistency graph over the descriptor matches of a pair is a dense bit
+ * matrix (n x n / 8 bytes), sized for at most this many matches, i.e. 13,107 source keypoints; a pair
+ * beyond it goes to GICP from its odometry guess and is counted in
+ * lgicp_stats.teaser_oversized_pairs (the reference runs TEASER++ at any size,
+ * IcpLoopComputation.cc:996-1054; with its Harris radius a keyed scan yields a few hundred to a
+ * few thousand keypoints) */
+#define LGICP_TEASER_MAX_MATCHES 65536
 /* IcpLoopComputation::IcpCovarianceMethod (IcpLoopComputation.h:144) */
 enum { LGICP_COV_POINT2POINT = 0, LGICP_COV_POINT2PLANE = 1 };
 
@@ -189,6 +196,10 @@ typedef struct lgicp_stats {
   uint64_t core_launches;
   double core_ms;               /* core_peel_group_kernel */
   double core_matrix_bytes;     /* the bit matrix of every graph, once */
+  uint64_t teaser_oversized_pairs; /* TEASERPP, last submit: pairs whose descriptor matches (5 per source
+                                   keypoint) exceeded LGICP_TEASER_MAX_MATCHES; such a pair keeps its
+                                   odometry guess, as a pair whose TEASER++ transform is not better
+                                   than the guess does (IcpLoopComputation.cc:1065-1074) */
 } lgicp_stats;
 
 typedef struct lgicp_ctx lgicp_ctx;
@@ -231,6 +242,12 @@ int lgicp_has_pose(const lgicp_ctx* ctx, uint64_t key);
  * reference's ThreadPool, ThreadPool.h:17-115, does with host threads).  out[n] is caller
  * allocated; out[i] belongs to cand[i].  Blocking, like the reference's future.wait() loop. */
 int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n, lgicp_result* out);
+/* The same, and the statistics of THIS submit in *submit_stats (may be NULL): with several submits
+ * in flight (lgicp_set_submit_lanes) lgicp_get_stats' "last submit" fields belong to whichever
+ * submit ended last.  Cumulative fields (pairs_submitted, outer_iterations, nn_launches,
+ * nn_distance_evals) hold this submit's share. */
+int lgicp_submit_stats(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n, lgicp_result* out,
+                       lgicp_stats* submit_stats);
 /* How many lgicp_submit calls of different host threads run side by side on the context (1..8;
  * default 1: a submit has the whole context, a second caller waits).  The reference spreads the
  * candidates of a tick over a pool of host threads (IcpLoopComputation.cc:327-365, ThreadPool.h);

@@ -16,7 +16,7 @@ SOLVER_GAUSS_NEWTON, SOLVER_BFGS = 0, 1
 
 EXPORTS = ["lgicp_default_config", "lgicp_create", "lgicp_destroy", "lgicp_last_error",
            "lgicp_add_keyframe", "lgicp_add_pose", "lgicp_has_keyframe", "lgicp_has_pose",
-           "lgicp_submit", "lgicp_get_stats", "lgicp_nn_search", "lgicp_covariances_from_normals",
+           "lgicp_submit", "lgicp_submit_stats", "lgicp_get_stats", "lgicp_nn_search", "lgicp_covariances_from_normals",
            "lgicp_covariances_knn", "lgicp_align", "lgicp_compute_ap", "lgicp_fpfh",
            "lgicp_harris_keypoints", "lgicp_sac_initial_alignment",
            "lgicp_teaser_initial_alignment", "lgicp_compute_normals", "lgicp_icp_observability",
@@ -70,7 +70,8 @@ class Stats(C.Structure):
                 ("reduce_launches", C.c_uint64), ("cycle_exits", C.c_uint64),
                 ("clique_ms", C.c_double), ("clique_row_bytes", C.c_double),
                 ("clique_launches", C.c_uint64), ("core_launches", C.c_uint64),
-                ("core_ms", C.c_double), ("core_matrix_bytes", C.c_double)]
+                ("core_ms", C.c_double), ("core_matrix_bytes", C.c_double),
+                ("teaser_oversized_pairs", C.c_uint64)]
 
 
 class LgicpError(RuntimeError):
@@ -102,6 +103,7 @@ def lib():
         L.lgicp_has_keyframe.argtypes = [C.c_void_p, C.c_uint64]
         L.lgicp_has_pose.argtypes = [C.c_void_p, C.c_uint64]
         L.lgicp_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lgicp_submit_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.lgicp_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.lgicp_set_submit_lanes.argtypes = [C.c_void_p, C.c_int]
         L.lgicp_nn_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
@@ -239,9 +241,16 @@ class Context:
         self._check(lib().lgicp_submit(self._h, arr, n, out))
         return out
 
+    def submit_packed_stats(self, packed):
+        """lgicp_submit_stats: the lgicp_result array and the statistics of this very submit."""
+        arr, n, out = packed
+        st = Stats()
+        self._check(lib().lgicp_submit_stats(self._h, arr, n, out, C.byref(st)))
+        return out, st
+
     def set_submit_lanes(self, lanes):
-        """lgicp_set_submit_lanes: submits of different threads that may run side by side (1 or 2);
-        returns the number in effect."""
+        """lgicp_set_submit_lanes: submits of different threads that may run side by side (1..8; at
+        most 2 for a context with a feature-based initialisation); returns the number in effect."""
         return self._check(lib().lgicp_set_submit_lanes(self._h, lanes))
 
     def submit(self, candidates):

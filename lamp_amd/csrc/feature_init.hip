@@ -449,7 +449,7 @@ int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudF
   job->n_matches = n;
   if (n <= 10) return LGICP_OK;  // IcpLoopComputation.cc:1002
   // the consistency graph is a dense n x n bit matrix: 65536 matches are 512 MiB of rows
-  constexpr int kMaxMatches = 65536;
+  constexpr int kMaxMatches = LGICP_TEASER_MAX_MATCHES;
   if (n > kMaxMatches) {
     // a per-pair outcome, not a call-level error: the pair keeps its odometry guess (what the
     // reference does whenever TEASER++ does not produce a better transform,
@@ -522,7 +522,8 @@ void teaser_prepare_collect(TeaserJob* job) {
 // work spread over threads.  T_out[i] is the guess unless the TEASER++
 // transform scores at least as well over the matches.
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
-                        float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times, hipStream_t st) {
+                        float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times, hipStream_t st,
+                        int fset) {
   namespace tz = lgicp::teaser;
   for (int i = 0; i < count; ++i) {
     std::memcpy(T_out[i], guesses[i], sizeof(float) * 16);
@@ -543,7 +544,8 @@ int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* con
       else
         on_host.push_back(i);
     }
-    if (on_device && !greedy_clique_group(ctx->cfg.device, st, graphs.data(), count, cliques.data(), times,
+    if (on_device && !greedy_clique_group(&ctx->clique_bufs[fset + 1], ctx->cfg.device, st, graphs.data(), count,
+                                          cliques.data(), times,
                                           ctx->cfg.reserved[4] == -2))
       return fail(ctx, LGICP_E_HIP, "TEASER++ initialisation: clique search over %d graphs (up to %d matches) "
                   "failed on the device (%s)", on_device, largest, hipGetErrorString(hipGetLastError()));

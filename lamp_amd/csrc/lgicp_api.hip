@@ -36,22 +36,37 @@ namespace lgicp_detail {
 
 static std::mutex g_parked_mutex;
 static std::vector<void*> g_parked, g_parked_pinned;
+thread_local lgicp_ctx* t_park_ctx = nullptr;
 
 void park_device_memory(void* p) {
   if (!p) return;
+  if (lgicp_ctx* c = t_park_ctx) {
+    std::lock_guard<std::mutex> lk(c->parked_mu);
+    c->parked_dev.push_back(p);
+    return;
+  }
   std::lock_guard<std::mutex> lk(g_parked_mutex);
   g_parked.push_back(p);
 }
 
 void park_pinned_memory(void* p) {
   if (!p) return;
+  if (lgicp_ctx* c = t_park_ctx) {
+    std::lock_guard<std::mutex> lk(c->parked_mu);
+    c->parked_pinned.push_back(p);
+    return;
+  }
   std::lock_guard<std::mutex> lk(g_parked_mutex);
   g_parked_pinned.push_back(p);
 }
 
-void free_parked_device_memory() {
+void free_parked_device_memory(lgicp_ctx* ctx) {
   std::vector<void*> dev, pinned;
-  {
+  if (ctx) {
+    std::lock_guard<std::mutex> lk(ctx->parked_mu);
+    dev.swap(ctx->parked_dev);
+    pinned.swap(ctx->parked_pinned);
+  } else {
     std::lock_guard<std::mutex> lk(g_parked_mutex);
     dev.swap(g_parked);
     pinned.swap(g_parked_pinned);
@@ -279,16 +294,21 @@ int lgicp_create(const lgicp_config* cfg, lgicp_ctx** out) {
                                                          std::default_delete<FeatureScratch[]>());
   ctx->sac_lanes = std::shared_ptr<SacLane>(new SacLane[lgicp_ctx::FEATURE_SETS * FEATURE_LANES],
                                             std::default_delete<SacLane[]>());
-  ctx->helpers[0].start(ctx->n_slots - 1);
+  ctx->helpers[0].start(ctx->n_slots - 1, ctx);
   *out = ctx;
   return LGICP_OK;
 }
 
 void lgicp_destroy(lgicp_ctx* ctx) {
-  free_parked_device_memory();
+  free_parked_device_memory(nullptr);
   if (!ctx) return;
   for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->helpers[l].shutdown();
   (void)hipSetDevice(ctx->cfg.device);
+  free_parked_device_memory(ctx);
+  for (CliqueBuffers*& b : ctx->clique_bufs) {
+    clique_buffers_delete(b);
+    b = nullptr;
+  }
   for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
   for (auto& kv : ctx->scans) kv.second.free_device();
   ctx->reg.destroy();
@@ -320,7 +340,8 @@ namespace {
 // starts.  Outgrown device buffers parked by earlier submits are freed on the way in.
 struct AllLanes {
   lgicp_ctx* ctx;
-  explicit AllLanes(lgicp_ctx* c) : ctx(c) {
+  ParkScope park;
+  explicit AllLanes(lgicp_ctx* c) : ctx(c), park(c) {
     std::unique_lock<std::mutex> lk(ctx->lane_mu);
     ctx->lane_cv.wait(lk, [&] {
       for (int l = 0; l < ctx->n_lanes; ++l)
@@ -328,7 +349,7 @@ struct AllLanes {
       return true;
     });
     for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->lane_busy[l] = true;
-    free_parked_device_memory();
+    free_parked_device_memory(ctx);
   }
   ~AllLanes() {
     {
@@ -344,8 +365,9 @@ struct AllLanes {
 // single submit can use, callers that overlap get one lane each.
 struct OneLane {
   lgicp_ctx* ctx;
+  ParkScope park;
   int lane = 0, held = 1;
-  OneLane(lgicp_ctx* c, int wide) : ctx(c) {
+  OneLane(lgicp_ctx* c, int wide) : ctx(c), park(c) {
     std::unique_lock<std::mutex> lk(ctx->lane_mu);
     ctx->lane_cv.wait(lk, [&] {
       for (int l = 0; l < ctx->n_lanes; ++l)
@@ -355,7 +377,7 @@ struct OneLane {
     bool any_busy = false;
     for (int l = 0; l < ctx->n_lanes; ++l) any_busy = any_busy || ctx->lane_busy[l];
     // outgrown buffers may still be read by what another lane has in flight
-    if (!any_busy) free_parked_device_memory();
+    if (!any_busy) free_parked_device_memory(ctx);
     if (!any_busy && wide > 1) {
       held = std::min(wide, ctx->n_lanes);
     } else {
@@ -456,7 +478,7 @@ int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes) {
   ctx->n_lanes = lanes;
   // (lane 0's helpers also serve a lone submit that is given several lanes)
   for (int l = 0; l < lanes; ++l)
-    ctx->helpers[l].start(feature_init ? 0 : std::max(ctx->n_slots / lanes, l == 0 ? ctx->n_wide : 1) - 1);
+    ctx->helpers[l].start(feature_init ? 0 : std::max(ctx->n_slots / lanes, l == 0 ? ctx->n_wide : 1) - 1, ctx);
   return lanes;
 }
 
@@ -751,15 +773,26 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
         if (rc != LGICP_OK) rc_all.store(rc);
       }
     };
+    auto run_parked = [&](int lane) {  // on a thread of its own: buffers it outgrows stay with ctx
+      ParkScope park(ctx);
+      run(lane);
+    };
     std::vector<std::thread> pool;
-    for (int l = 1; l < lanes; ++l) pool.emplace_back(run, l);
+    for (int l = 1; l < lanes; ++l) pool.emplace_back(run_parked, l);
     run(0);
     for (std::thread& t : pool) t.join();
     if (rc_all.load() != LGICP_OK) {
       // nothing half-made stays behind on a keyframe
       for (int c : todo)
         if (!bp.clouds[c].accumulated) ctx->scans.at(bp.clouds[c].key).features.reset();
-      if (rc_all.load() == LGICP_E_HIP && ctx->err.empty()) fail(ctx, LGICP_E_HIP, "feature front end failed");
+      {
+        bool no_text;
+        {
+          std::lock_guard<std::mutex> lock(ctx->err_mu);  // other lanes may be setting a message
+          no_text = ctx->err.empty();
+        }
+        if (rc_all.load() == LGICP_E_HIP && no_text) fail(ctx, LGICP_E_HIP, "feature front end failed");
+      }
       return rc_all.load();
     }
   }
@@ -845,17 +878,23 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
       const auto t_b = std::chrono::steady_clock::now();
       std::thread helper;
       nxt->count = 0, nxt->rc = LGICP_OK;
-      if (q < n_pairs) helper = std::thread([&] { prepare(*nxt, half ^ 1, true); });
+      if (q < n_pairs)
+        helper = std::thread([&] {
+          ParkScope park(ctx);
+          prepare(*nxt, half ^ 1, true);
+        });
       const int g = cur->count;
       float T0[kGroup][16];
       int used[kGroup], nc[kGroup];
       CliqueTimes ct;
-      const int rc = teaser_finish_group(ctx, cur->jobs, cur->guesses, g, T0, used, nc, &ct, main_stream);
+      const int rc = teaser_finish_group(ctx, cur->jobs, cur->guesses, g, T0, used, nc, &ct, main_stream, fset);
       if (helper.joinable()) helper.join();
       stats.clique_ms += ct.starts_ms, stats.clique_row_bytes += ct.starts_row_bytes;
       stats.clique_launches += ct.starts_launches;
       stats.core_ms += ct.core_ms, stats.core_matrix_bytes += ct.core_matrix_bytes;
       stats.core_launches += ct.core_launches;
+      for (int j = 0; j < g; ++j)
+        stats.teaser_oversized_pairs += cur->jobs[j]->n_matches > LGICP_TEASER_MAX_MATCHES;
       if (rc != LGICP_OK) return rc;
       for (int j = 0; j < g; ++j) {
         const int p = cur->pair[j];
@@ -910,8 +949,12 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
         if (!h_state[p].active) std::memcpy(h_state[p].Tfinal, T0, sizeof(T0));
       }
     };
+    auto run_parked = [&](int lane) {
+      ParkScope park(ctx);
+      run(lane);
+    };
     std::vector<std::thread> pool;
-    for (int l = 1; l < lanes; ++l) pool.emplace_back(run, l);
+    for (int l = 1; l < lanes; ++l) pool.emplace_back(run_parked, l);
     run(0);
     for (std::thread& t : pool) t.join();
     if (rc_all.load() != LGICP_OK) return rc_all.load();
@@ -1539,6 +1582,7 @@ void merge_stats(lgicp_stats& into, const lgicp_stats& d) {
   into.clique_launches += d.clique_launches;
   into.core_ms += d.core_ms, into.core_matrix_bytes += d.core_matrix_bytes;
   into.core_launches += d.core_launches;
+  into.teaser_oversized_pairs += d.teaser_oversized_pairs;
   if (d.last_nn_evals_per_launch > 0) {
     into.last_nn_kernel_ms = d.last_nn_kernel_ms;
     into.last_nn_evals_per_launch = d.last_nn_evals_per_launch;
@@ -1552,12 +1596,19 @@ void reset_submit_stats(lgicp_stats& s) {
   s.cycle_exits = 0;
   s.clique_ms = s.clique_row_bytes = s.core_ms = s.core_matrix_bytes = 0;
   s.clique_launches = s.core_launches = 0;
+  s.teaser_oversized_pairs = 0;
 }
 
 }  // namespace
 
 extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n,
                             lgicp_result* out) {
+  return lgicp_submit_stats(ctx, cand, n, out, nullptr);
+}
+
+extern "C" int lgicp_submit_stats(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t n,
+                                  lgicp_result* out, lgicp_stats* submit_stats) {
+  if (submit_stats) std::memset(submit_stats, 0, sizeof(*submit_stats));
   if (!ctx) return LGICP_E_INVALID;
   if (n && (!cand || !out)) return fail(ctx, LGICP_E_INVALID, "null argument");
   const lgicp_config& cfg = ctx->cfg;
@@ -1713,6 +1764,7 @@ extern "C" int lgicp_submit(lgicp_ctx* ctx, const lgicp_candidate* cand, size_t 
     ctx->stats.pairs_submitted += sub.pairs_submitted;
     ctx->stats.total_ms = sub.total_ms;
   }
+  if (submit_stats) *submit_stats = sub;
   return rc_all;
 }
 

@@ -23,11 +23,14 @@
 
 using namespace lgicp;
 
+struct lgicp_ctx;
+
 namespace lgicp_detail {
 
 inline std::string g_create_error;
 
 struct CloudFeatures;
+struct CliqueBuffers;
 struct TeaserJob;
 struct MatcherDev;
 struct FeatureScratch;
@@ -80,11 +83,23 @@ struct Keyframe {
 // hipFree waits for all work of the device, whichever stream it is on: a buffer that is outgrown
 // in the middle of a submit (the groups of a feature-based initialisation differ from batch to
 // batch) would stall every stage running beside the caller, once per buffer.  Outgrown buffers are
-// parked instead and freed when the next submit begins (free_parked_device_memory), with nothing
-// of the context in flight.  Both are safe to call from any thread.
+// parked instead -- with the context the parking thread is working for (ParkScope) -- and freed when
+// a later submit of THAT context begins with nothing of the context in flight
+// (free_parked_device_memory(ctx)): another context of the process may be in the middle of a
+// submit then, and its parked buffers may still be read by its kernels.  A thread that works for
+// no context parks in a process-wide list, freed by whichever context is destroyed next.  All
+// three are safe to call from any thread.
 void park_device_memory(void* p);
 void park_pinned_memory(void* p);  // same for hipHostMalloc'ed memory
-void free_parked_device_memory();
+void free_parked_device_memory(struct ::lgicp_ctx* ctx);  // ctx == nullptr: the process-wide list only
+extern thread_local struct ::lgicp_ctx* t_park_ctx;
+struct ParkScope {  // the calling thread works for `c` while this exists
+  struct ::lgicp_ctx* prev;
+  explicit ParkScope(struct ::lgicp_ctx* c) : prev(t_park_ctx) { t_park_ctx = c; }
+  ~ParkScope() { t_park_ctx = prev; }
+  ParkScope(const ParkScope&) = delete;
+  ParkScope& operator=(const ParkScope&) = delete;
+};
 
 template <typename T>
 struct DevBuf {  // grow-only device array
@@ -213,11 +228,13 @@ struct SlotThreads {
   int pending = 0;
   bool stop = false;
 
-  void start(int n_helpers) {
+  // owner: the context the helpers work for (where the buffers they outgrow are parked)
+  void start(int n_helpers, struct ::lgicp_ctx* owner) {
     // a restarted set must not take the last job of the previous one for a new job
     const uint64_t born = generation;
     for (int k = 1; k <= n_helpers; ++k)
-      threads.emplace_back([this, k, born] {
+      threads.emplace_back([this, k, born, owner] {
+        ParkScope park(owner);
         uint64_t seen = born;
         for (;;) {
           std::function<void(int)> fn;
@@ -312,6 +329,12 @@ struct lgicp_ctx {
   std::shared_ptr<lgicp_detail::FeatureScratch> feature_scratch;  // [FEATURE_SETS * FEATURE_LANES]
   std::shared_ptr<lgicp_detail::SacLane> sac_lanes;               // [FEATURE_SETS * FEATURE_LANES]
   std::mutex feat_mu;  // Keyframe::features: looked up and filled by one submit at a time
+  // device and pinned buffers of the TEASER++ clique search: [0] the single-pair entry points (the
+  // context's stream), [1 + f] feature set f; created on first use, released by lgicp_destroy
+  lgicp_detail::CliqueBuffers* clique_bufs[FEATURE_SETS + 1] = {};
+  // outgrown buffers of this context, freed when one of its submits begins with nothing in flight
+  std::mutex parked_mu;
+  std::vector<void*> parked_dev, parked_pinned;
 };
 
 namespace lgicp_detail {
@@ -392,8 +415,11 @@ struct SacLane {
 };
 // teaser::greedy_clique on a bit matrix in device memory (teaser_graph.hip): core numbers and the
 // windows of starts run on `st`; false when the device refuses
-bool greedy_clique_device(int device, hipStream_t st, const unsigned long long* d_bits, int n, int words,
-                          std::vector<int>* clique);
+// (bufs: the working buffers, *bufs is created on first use and belongs to the caller, who
+// releases it with clique_buffers_delete while its device is current or not -- it switches itself)
+bool greedy_clique_device(CliqueBuffers** bufs, int device, hipStream_t st, const unsigned long long* d_bits,
+                          int n, int words, std::vector<int>* clique);
+void clique_buffers_delete(CliqueBuffers* b);
 // the same for `count` graphs at once (every launch carries a step of all of them); entries with
 // n == 0 are skipped and get an empty clique
 struct CliqueGraph {
@@ -406,8 +432,9 @@ struct CliqueTimes {  // hipEvent durations and algorithmic bytes of the two ker
 };
 // rerun_improving: ignore the member sets the windows kept and run every improving start once
 // more on its own (the fallback for a start that found no free slot; a switch for tests)
-bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* graphs, int count,
-                         std::vector<int>* cliques, CliqueTimes* times = nullptr, bool rerun_improving = false);
+bool greedy_clique_group(CliqueBuffers** bufs, int device, hipStream_t st, const CliqueGraph* graphs,
+                         int count, std::vector<int>* cliques, CliqueTimes* times = nullptr,
+                         bool rerun_improving = false);
 int clique_device_max_vertices();
 // first half: enqueues matcher and consistency graph of one pair on the context's stream and
 // returns; teaser_prepare_collect (after the stream has been synchronised) moves the matched
@@ -418,10 +445,11 @@ int clique_device_max_vertices();
 int teaser_prepare_device(lgicp_ctx* ctx, const CloudFeatures& src, const CloudFeatures& tgt,
                           TeaserJob* job, hipStream_t st = nullptr, int fset = 0, int sub = 0);
 void teaser_prepare_collect(TeaserJob* job);
-// (st: the stream of the clique search, the context's own when null)
+// (st: the stream of the clique search, the context's own when null; fset: whose clique-search
+// buffers the call uses, -1 = those of the single-pair entry points)
 int teaser_finish_group(lgicp_ctx* ctx, TeaserJob* const* jobs, const float* const* guesses, int count,
                         float (*T_out)[16], int* used, int* n_clique, CliqueTimes* times = nullptr,
-                        hipStream_t st = nullptr);
+                        hipStream_t st = nullptr, int fset = -1);
 
 // device address of the static scratch array behind lgicp_nn_search_static, looked up once per
 // device; `device` must be the current device

@@ -397,7 +397,8 @@ int lgicp_teaser_clique(lgicp_ctx* ctx, const uint64_t* adjacency, size_t n, int
     return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
   std::vector<int> clique;
   bool ok = hipMemcpy(d_bits, adjacency, sizeof(uint64_t) * n * words, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && greedy_clique_device(ctx->cfg.device, ctx->stream, d_bits, (int)n, (int)words, &clique);
+  ok = ok && greedy_clique_device(&ctx->clique_bufs[0], ctx->cfg.device, ctx->stream, d_bits, (int)n, (int)words,
+                                  &clique);
   (void)hipFree(d_bits);
   if (!ok) return fail(ctx, LGICP_E_HIP, "clique search on the device failed (%s)", hipGetErrorString(hipGetLastError()));
   for (size_t i = 0; i < clique.size(); ++i) clique_out[i] = clique[i];

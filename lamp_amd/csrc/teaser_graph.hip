@@ -413,8 +413,11 @@ struct PinBuf {  // grow-only pinned host array
   }
 };
 
-// buffers of the clique search, one set per host thread and device, reused from group to group
-struct CliqueGroupDev {
+}  // namespace
+
+// buffers of the clique search, reused from group to group; a context owns one set per feature set
+// (one clique search runs on a set at a time)
+struct CliqueBuffers {
   int device = -1;
   DevBuf<unsigned short> c, pref;
   DevBuf<unsigned long long> elig, sets;
@@ -440,8 +443,11 @@ struct CliqueGroupDev {
     }
     device = -1;
   }
-  ~CliqueGroupDev() { release(); }
+  ~CliqueBuffers() { release(); }
 };
+void clique_buffers_delete(CliqueBuffers* b) { delete b; }
+
+namespace {
 constexpr int kMaxWindow = 65536;
 // Windows of 1, 256 and 65,536 starts: a window lasts at least as long as its longest walk (the
 // first start's, which finds a clique of hundreds to thousands of members step by step, and every
@@ -460,8 +466,8 @@ int clique_device_max_vertices() { return 65536; }
 // teaser::greedy_clique on `count` bit matrices in device memory, all of them advancing together.
 // Entries with n == 0 are skipped.  Returns false when the device refuses; cliques[i] comes back
 // sorted ascending, equal to the host function's result for graph i.
-bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int count, std::vector<int>* cliques,
-                         CliqueTimes* times, bool rerun_improving) {
+bool greedy_clique_group(CliqueBuffers** bufs, int device, hipStream_t st, const CliqueGraph* gr, int count,
+                         std::vector<int>* cliques, CliqueTimes* times, bool rerun_improving) {
   using lgicp::GraphDev;
   for (int i = 0; i < count; ++i) cliques[i].clear();
   std::vector<int> ids;
@@ -474,7 +480,8 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   }
   const int P = (int)ids.size();
   if (P == 0) return true;
-  thread_local CliqueGroupDev B;
+  if (!*bufs) *bufs = new CliqueBuffers();
+  CliqueBuffers& B = **bufs;
   if (B.device != device) {
     B.release();
     if (hipSetDevice(device) != hipSuccess) return false;
@@ -762,10 +769,11 @@ bool greedy_clique_group(int device, hipStream_t st, const CliqueGraph* gr, int 
   return true;
 }
 
-bool greedy_clique_device(int device, hipStream_t st, const unsigned long long* d_bits, int n, int words,
+bool greedy_clique_device(CliqueBuffers** bufs, int device, hipStream_t st, const unsigned long long* d_bits,
+                          int n, int words,
                           std::vector<int>* clique) {
   const CliqueGraph g{d_bits, n, words};
-  return greedy_clique_group(device, st, &g, 1, clique);
+  return greedy_clique_group(bufs, device, st, &g, 1, clique);
 }
 
 }  // namespace lgicp_detail

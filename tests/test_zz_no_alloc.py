@@ -22,7 +22,13 @@ class _Hip:
         self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         self.rt.hipDeviceSynchronize.argtypes = []
+        self.rt.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         self.live = []
+
+    def free_bytes(self):
+        free, total = C.c_size_t(), C.c_size_t()
+        assert self.rt.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
 
     def upload(self, a):
         a = np.ascontiguousarray(a)
@@ -63,7 +69,10 @@ def _check(ctx, hip, T, src, tgt):
     ref_idx, ref_d2 = ctx.nn_search(T, src, tgt, 0)
     d_src, d_tgt = hip.upload(src), hip.upload(tgt)
     d_idx, d_d2 = hip.empty(4 * len(src)), hip.empty(4 * len(src))
+    # the entry point's contract: no device allocation inside the call, none left behind
+    before = hip.free_bytes()
     ctx.nn_search_static(T, d_src, len(src), d_tgt, len(tgt), d_idx, d_d2)
+    assert hip.free_bytes() == before
     idx = hip.download(d_idx, np.int32, len(src))
     d2 = hip.download(d_d2, np.float32, len(src))
     assert np.array_equal(idx, ref_idx)
