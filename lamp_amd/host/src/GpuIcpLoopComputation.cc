@@ -5,13 +5,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace lamp_loop_closure {
 
 GpuIcpLoopComputation::GpuIcpLoopComputation() { lgicp_default_config(&cfg_, 1); }
 
 GpuIcpLoopComputation::~GpuIcpLoopComputation() {
-  if (ctx_) lgicp_destroy(ctx_);
+  for (lgicp_ctx* c : ctxs_) lgicp_destroy(c);
 }
 
 const char* GpuIcpLoopComputation::last_error() const { return lgicp_last_error(ctx_); }
@@ -25,16 +26,29 @@ bool GpuIcpLoopComputation::Initialize(const NodeHandle& n) {
   }
   if (!RegisterCallbacks(n)) return false;
   if (!CreatePublishers(n)) return false;
-  if (ctx_) {
-    lgicp_destroy(ctx_);
-    ctx_ = nullptr;
-    keyed_scans_.clear();
-    closed_keyes_.clear();
+  for (lgicp_ctx* c : ctxs_) lgicp_destroy(c);
+  ctxs_.clear();
+  ctx_ = nullptr;
+  keyed_scans_.clear();
+  closed_keyes_.clear();
+  host_scans_.clear();
+  registered_.clear();
+  std::vector<int> devices = devices_;
+  if (devices.empty()) devices.push_back(cfg_.device);
+  for (int d : devices) {
+    lgicp_config cfg = cfg_;
+    cfg.device = d;
+    lgicp_ctx* c = nullptr;
+    if (lgicp_create(&cfg, &c) != LGICP_OK) {
+      std::fprintf(stderr, "GpuIcpLoopComputation: device %d: %s\n", d, lgicp_last_error(nullptr));
+      for (lgicp_ctx* made : ctxs_) lgicp_destroy(made);
+      ctxs_.clear();
+      return false;
+    }
+    ctxs_.push_back(c);
   }
-  if (lgicp_create(&cfg_, &ctx_) != LGICP_OK) {
-    std::fprintf(stderr, "GpuIcpLoopComputation: %s\n", lgicp_last_error(nullptr));
-    return false;
-  }
+  ctx_ = ctxs_[0];
+  registered_.resize(ctxs_.size());
   return true;
 }
 
@@ -76,6 +90,11 @@ bool GpuIcpLoopComputation::LoadParameters(const NodeHandle& n) {
   if (!pu.GetAs("b_use_fixed_covariances", cfg_.use_fixed_covariances)) return false;
   double pool;  // host thread pool size of the reference: replaced by the device batch
   if (!pu.Get(ns + "/icp_thread_pool_thread_count", pool)) return false;
+  // not in the reference (optional): the inner solver, and how many GPUs share the candidates
+  pu.GetAs(ns + "/icp_lc/solver", cfg_.solver);
+  int gpu_devices = 0;
+  if (devices_.empty() && pu.GetAs(ns + "/gpu_devices", gpu_devices) && gpu_devices > 1)
+    for (int d = 0; d < gpu_devices; ++d) devices_.push_back(d);
   return true;
 }
 
@@ -89,6 +108,12 @@ bool GpuIcpLoopComputation::RegisterCallbacks(const NodeHandle& n) {
 // IcpLoopComputation::KeyedScanCallback (IcpLoopComputation.cc:377-392): first scan wins
 void GpuIcpLoopComputation::KeyedScanCallback(const pose_graph_msgs::KeyedScan& m) {
   if (keyed_scans_.count(m.key)) return;
+  if (ctxs_.size() > 1) {
+    // which GPU needs the scan is known only when a candidate names it: keep it on the host
+    host_scans_.emplace(m.key, m.scan);
+    keyed_scans_.insert(m.key);
+    return;
+  }
   const pose_graph_msgs::PointXYZINormal* p = m.scan.data();
   const float* xyz = p ? &p->x : nullptr;
   const float* nrm = p ? &p->normal_x : nullptr;
@@ -103,7 +128,7 @@ void GpuIcpLoopComputation::KeyedPoseCallback(const pose_graph_msgs::PoseGraph& 
     const double q[4] = {node.pose.orientation.w, node.pose.orientation.x,
                          node.pose.orientation.y, node.pose.orientation.z};
     const double t[3] = {node.pose.position.x, node.pose.position.y, node.pose.position.z};
-    lgicp_add_pose(ctx_, node.key, q, t);
+    for (lgicp_ctx* c : ctxs_) lgicp_add_pose(c, node.key, q, t);  // 56 bytes: every device keeps all
   }
 }
 
@@ -205,22 +230,10 @@ void GpuIcpLoopComputation::ComputeTransforms() {
   std::vector<lgicp_candidate> cands(batch.size());
   std::vector<lgicp_result> results(batch.size());
   for (size_t i = 0; i < batch.size(); ++i) fill_candidate(batch[i], &cands[i]);
-  if (lgicp_submit(ctx_, cands.data(), cands.size(), results.data()) != LGICP_OK) {
-    // The reference fails per pair and never loses the rest of its queue (every `return false` of
-    // PerformAlignment drops one candidate): a call-level error of the batch is retried one
-    // candidate at a time, so that only the candidates the engine cannot process are dropped.
-    std::fprintf(stderr, "GpuIcpLoopComputation: batch of %zu failed (%s); retrying per candidate\n",
-                 batch.size(), lgicp_last_error(ctx_));
-    for (size_t i = 0; i < batch.size(); ++i) {
-      if (lgicp_submit(ctx_, &cands[i], 1, &results[i]) == LGICP_OK) continue;
-      std::fprintf(stderr, "GpuIcpLoopComputation: candidate %llu -> %llu dropped: %s\n",
-                   (unsigned long long)cands[i].key_from, (unsigned long long)cands[i].key_to,
-                   lgicp_last_error(ctx_));
-      results[i].key_from = cands[i].key_from;
-      results[i].key_to = cands[i].key_to;
-      results[i].status = LGICP_PAIR_NOT_CONVERGED;
-    }
-  }
+  if (ctxs_.size() > 1)
+    SubmitSharded(cands, &results);
+  else
+    SubmitOne(ctx_, cands.data(), cands.size(), results.data());
   for (size_t i = 0; i < batch.size(); ++i) {
     const lgicp_result& r = results[i];
     if (!CheckReclosingDistance(r.key_from, r.key_to)) continue;
@@ -235,6 +248,86 @@ void GpuIcpLoopComputation::ComputeTransforms() {
     loop_closure.range_error = r.fitness;
     output_queue_.push_back(loop_closure);
   }
+}
+
+// One blocking batch on one context.  The reference fails per pair and never loses the rest of its
+// queue (every `return false` of PerformAlignment drops one candidate): a call-level error of the
+// batch is retried one candidate at a time, so that only the candidates the engine cannot process
+// are dropped.
+void GpuIcpLoopComputation::SubmitOne(lgicp_ctx* ctx, lgicp_candidate* cands, size_t n,
+                                      lgicp_result* results) {
+  if (n == 0 || lgicp_submit(ctx, cands, n, results) == LGICP_OK) return;
+  std::fprintf(stderr, "GpuIcpLoopComputation: batch of %zu failed (%s); retrying per candidate\n", n,
+               lgicp_last_error(ctx));
+  for (size_t i = 0; i < n; ++i) {
+    if (lgicp_submit(ctx, &cands[i], 1, &results[i]) == LGICP_OK) continue;
+    std::fprintf(stderr, "GpuIcpLoopComputation: candidate %llu -> %llu dropped: %s\n",
+                 (unsigned long long)cands[i].key_from, (unsigned long long)cands[i].key_to,
+                 lgicp_last_error(ctx));
+    results[i].key_from = cands[i].key_from;
+    results[i].key_to = cands[i].key_to;
+    results[i].status = LGICP_PAIR_NOT_CONVERGED;
+  }
+}
+
+// The candidates of a tick cut over the contexts (the reference's pool of PerformAlignment workers,
+// IcpLoopComputation.cc:327-365, across GPUs): partition by cost with affinity to the scans a
+// device already holds, register what each device is missing -- the two scans of its pairs and the
+// neighbours AccumulateScans will look for (IcpLoopComputation.cc:910-947: key +- i for the target,
+// and for the source when b_accumulate_source is set) --, submit from one thread per context, and
+// put the results back in queue order.
+void GpuIcpLoopComputation::SubmitSharded(const std::vector<lgicp_candidate>& cands,
+                                          std::vector<lgicp_result>* results) {
+  const size_t world = ctxs_.size();
+  std::vector<PairKeys> pairs(cands.size());
+  for (size_t i = 0; i < cands.size(); ++i) pairs[i] = {cands[i].key_from, cands[i].key_to};
+  auto cloud_size = [&](uint64_t key) {
+    auto it = host_scans_.find(key);
+    return it == host_scans_.end() ? size_t{0} : it->second.size();
+  };
+  std::vector<std::set<uint64_t>> held = registered_;
+  const std::vector<std::vector<size_t>> share = PartitionPairs(pairs, cloud_size, (int)world, &held);
+  std::vector<std::thread> workers;
+  for (size_t d = 0; d < world; ++d) {
+    if (share[d].empty()) continue;
+    workers.emplace_back([&, d] {
+      // scans device d is missing
+      std::set<uint64_t> need;
+      auto with_neighbours = [&](uint64_t key, bool accumulate) {
+        need.insert(key);
+        if (!accumulate) return;
+        for (int i = 1; i <= cfg_.num_prev_scans; ++i)
+          if (key >= (uint64_t)i) need.insert(key - i);
+        for (int i = 1; i <= cfg_.num_next_scans; ++i) need.insert(key + i);
+      };
+      for (size_t i : share[d]) {
+        with_neighbours(cands[i].key_to, true);
+        with_neighbours(cands[i].key_from, cfg_.accumulate_source != 0);
+      }
+      std::vector<uint64_t> keys;
+      std::vector<const float*> xyz, nrm;
+      std::vector<size_t> counts;
+      for (uint64_t k : need) {
+        auto it = host_scans_.find(k);
+        if (it == host_scans_.end() || registered_[d].count(k)) continue;
+        const pose_graph_msgs::PointXYZINormal* p = it->second.data();
+        keys.push_back(k);
+        xyz.push_back(p ? &p->x : nullptr);
+        nrm.push_back(p ? &p->normal_x : nullptr);
+        counts.push_back(it->second.size());
+      }
+      if (!keys.empty() &&
+          lgicp_add_keyframes(ctxs_[d], keys.size(), keys.data(), xyz.data(), nrm.data(), counts.data(),
+                              sizeof(pose_graph_msgs::PointXYZINormal)) >= 0)
+        registered_[d].insert(keys.begin(), keys.end());
+      std::vector<lgicp_candidate> mine(share[d].size());
+      std::vector<lgicp_result> out(share[d].size());
+      for (size_t j = 0; j < share[d].size(); ++j) mine[j] = cands[share[d][j]];
+      SubmitOne(ctxs_[d], mine.data(), mine.size(), out.data());
+      for (size_t j = 0; j < share[d].size(); ++j) (*results)[share[d][j]] = out[j];
+    });
+  }
+  for (std::thread& t : workers) t.join();
 }
 
 void GpuIcpLoopComputation::ProcessTimerCallback() {
@@ -257,7 +350,14 @@ bool GpuIcpLoopComputation::PerformAlignment(uint64_t key1, uint64_t key2,
   lgicp_candidate lc;
   lgicp_result r;
   fill_candidate(c, &lc);
-  if (lgicp_submit(ctx_, &lc, 1, &r) != LGICP_OK) return false;
+  if (ctxs_.size() > 1) {
+    std::vector<lgicp_candidate> one(1, lc);
+    std::vector<lgicp_result> res(1);
+    SubmitSharded(one, &res);
+    r = res[0];
+  } else if (lgicp_submit(ctx_, &lc, 1, &r) != LGICP_OK) {
+    return false;
+  }
   // delta is filled before the gates in the reference (:568-577): give the ICP transform
   for (int a = 0; a < 3; ++a) {
     for (int b = 0; b < 3; ++b) delta->rotation[a * 3 + b] = r.T_icp[a * 4 + b];

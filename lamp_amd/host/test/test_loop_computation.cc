@@ -102,6 +102,42 @@ static void HostOnly() {
   };
   icp.PublishLoopClosures();
   CHECK(status_count == 1);
+  // PartitionPairs: equal costs balance, pairs follow the device that holds their keyframes
+  {
+    auto size = [](uint64_t) { return size_t{1000}; };
+    std::vector<PairKeys> p = {{1, 2}, {3, 4}, {1, 5}, {3, 6}};
+    auto part = PartitionPairs(p, size, 2);
+    CHECK(part[0].size() == 2 && part[1].size() == 2);
+    CHECK(part[0][0] == 0 && part[0][1] == 2 && part[1][0] == 1 && part[1][1] == 3);
+    std::vector<std::set<uint64_t>> held = {{}, {1, 2}};
+    part = PartitionPairs({{1, 2}}, size, 2, &held);
+    CHECK(part[0].empty() && part[1].size() == 1);   // goes where its scans are
+    CHECK(PartitionPairs({}, size, 3).size() == 3);
+  }
+}
+
+// a deterministic candidate list for the comparison with lamp_amd/sharding.py: partition_pairs
+static void PrintPartition() {
+  uint64_t s = 12345;
+  auto next = [&] {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(s >> 33);
+  };
+  std::vector<size_t> sizes(40);
+  for (auto& v : sizes) v = 8000 + next() % 24000;
+  std::vector<PairKeys> pairs(200);
+  for (auto& p : pairs) {
+    p.key_from = next() % 40;
+    p.key_to = next() % 40;
+  }
+  auto part = PartitionPairs(pairs, [&](uint64_t k) { return sizes[k]; }, 3);
+  std::printf("{\"host_only\": true, \"partition\": [");
+  for (size_t r = 0; r < part.size(); ++r) {
+    std::printf("%s[", r ? ", " : "");
+    for (size_t j = 0; j < part[r].size(); ++j) std::printf("%s%zu", j ? ", " : "", part[r][j]);
+    std::printf("]");
+  }
+  std::printf("]}\n");
 }
 
 static void OnDevice() {
@@ -226,7 +262,39 @@ static void OnDevice() {
     icp.PublishLoopClosures();
     CHECK(published == (int)test_size && completed == 1);
     CHECK(icp.GetCurrentOutputQueue().empty());
-    std::printf("\"batch_edges\": %zu}\n", out.size());
+    std::printf("\"batch_edges\": %zu, ", out.size());
+    // The same tick over two engine contexts (both on device 0 here; one per GPU on a node with
+    // several): every candidate lands on exactly one context, each context holds only the scans
+    // of its own pairs, and the edges are the single-context edges bit for bit, in queue order.
+    Probe two;
+    two.SetDevices({0, 0});
+    CHECK(two.Initialize(nh));
+    CHECK(two.device_count() == 2);
+    for (uint64_t k = 0; k < test_size * 2; ++k)
+      two.KeyedScanCallback({10 * k, Shift(base, (k % 2) == 1 ? -1.0f : 1.0f, 0.f)});
+    two.KeyedPoseCallback(graph);
+    two.InputCallback(cands);
+    two.set_reclosing(0);
+    two.now_ = [&] { return 1e6; };
+    two.ComputeTransforms();
+    auto out2 = two.GetCurrentOutputQueue();
+    CHECK(out2.size() == out.size());
+    size_t same = 0;
+    for (size_t i = 0; i < out.size() && i < out2.size(); ++i)
+      same += out[i].key_from == out2[i].key_from && out[i].key_to == out2[i].key_to &&
+              std::memcmp(&out[i].pose, &out2[i].pose, sizeof(out[i].pose)) == 0 &&
+              out[i].covariance == out2[i].covariance &&
+              out[i].range_error == out2[i].range_error;
+    CHECK(same == out.size());
+    CHECK(two.resident_scans(0) + two.resident_scans(1) == 2 * test_size);  // no scan uploaded twice
+    CHECK(two.resident_scans(0) >= test_size / 2 && two.resident_scans(1) >= test_size / 2);
+    // a second tick over the same scans uploads nothing new
+    two.InputCallback(cands);
+    two.ComputeTransforms();
+    CHECK(two.GetCurrentOutputQueue().size() == 2 * out.size());
+    CHECK(two.resident_scans(0) + two.resident_scans(1) == 2 * test_size);
+    std::printf("\"two_context_edges_identical\": %zu, \"resident_scans\": [%zu, %zu]}\n", same,
+                two.resident_scans(0), two.resident_scans(1));
   }
 }
 
@@ -276,6 +344,6 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "%d check(s) failed\n", g_fail);
     return 1;
   }
-  if (host_only) std::printf("{\"host_only\": true}\n");
+  if (host_only) PrintPartition();
   return 0;
 }

@@ -69,3 +69,22 @@ def test_host_mirror_cpu_logic():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "lamp_amd", "host")])
     out = subprocess.check_output([exe, "--host-only"], timeout=60)
     assert b"host_only" in out
+    # the C++ cut of a candidate list over devices (loop_closure/PairSharding.h) equals the Python
+    # one the multi-process harness uses (lamp_amd/sharding.py), on the same pseudo-random list
+    import json
+    from lamp_amd.sharding import partition_pairs
+    got = json.loads(out.decode().strip().splitlines()[-1])["partition"]
+    state = [12345]
+
+    def nxt():
+        state[0] = (state[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        return state[0] >> 33
+
+    sizes = {k: 8000 + nxt() % 24000 for k in range(40)}
+    pairs = []
+    for _ in range(200):
+        a = nxt() % 40
+        b = nxt() % 40
+        pairs.append((a, b))
+    assert got == partition_pairs(pairs, sizes, 3)
+    assert sorted(i for part in got for i in part) == list(range(200))

@@ -363,6 +363,10 @@ def test_host_mirror_reference_style_tests():
     # the reference's own configuration of that test: base block untouched (FEATURES initialisation)
     t = d["perform_alignment_reference_defaults_t"]
     assert abs(t[0] - 1) < 1e-3 and abs(t[1] + 0.001) < 1e-3 and abs(t[2]) < 1e-3
+    # one tick cut over two engine contexts (GpuIcpLoopComputation::SetDevices): the single-context
+    # edges bit for bit, every scan resident on exactly one context
+    assert d["two_context_edges_identical"] == 100
+    assert sum(d["resident_scans"]) == 200 and min(d["resident_scans"]) >= 50
 
 
 def test_submit_point2point_covariance_matches_oracle():
