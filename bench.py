@@ -669,7 +669,8 @@ def main():
         subs["accumulated"] = sub_record(
             "C2", "C2 with consecutive keys: the base-station block accumulates key +- 2 into every "
             "target (IcpLoopComputation.cc:910-947, laser_parameters.yaml:255-256), targets of up to "
-            "5 x 16k points assembled and indexed inside every submit", consecutive_keys=True,
+            "5 x 16k points, built and indexed on the device the first time a candidate names them "
+            "(lgicp_config.accumulated_cache_bytes) and found there by later submits", consecutive_keys=True,
             exclusive_nn=True)
         progress("sub-record: accumulated targets done")
         subs["solver_bfgs"] = sub_record(

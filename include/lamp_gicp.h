@@ -122,6 +122,13 @@ typedef struct lgicp_config {
   int harris_response;
   /* device-side knobs with no counterpart in the reference */
   size_t workspace_bytes;     /* upper bound for per-batch device scratch (0 = 16 GiB) */
+  size_t accumulated_cache_bytes; /* Accumulated clouds (AccumulateScans: a keyframe plus its
+                                 neighbours key +- num_prev/next_scans in its frame) are kept on
+                                 the device with their own search index once a submit has built
+                                 them — keyed scans and poses never change once stored, so such a
+                                 cloud is a function of its keys — up to this many bytes, least
+                                 recently used first out (0 = 32 GiB, 1 = keep none: every submit
+                                 assembles its accumulated clouds afresh, results are the same) */
   int solver;                 /* LGICP_SOLVER_* (0 = Gauss-Newton) */
   int reserved[8];            /* tuning/diagnostics, 0 = default: [0] queries per lane of the
                                  exhaustive 1-NN kernel (2, 4, 8); [1] its target splits;

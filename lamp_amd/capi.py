@@ -40,7 +40,7 @@ class Config(C.Structure):
                 ("harris_threshold", C.c_double), ("harris_suppression", C.c_int),
                 ("harris_radius", C.c_double), ("harris_refine", C.c_int),
                 ("harris_response", C.c_int), ("workspace_bytes", C.c_size_t),
-                ("solver", C.c_int), ("reserved", C.c_int * 8)]
+                ("accumulated_cache_bytes", C.c_size_t), ("solver", C.c_int), ("reserved", C.c_int * 8)]
 
 
 class Candidate(C.Structure):

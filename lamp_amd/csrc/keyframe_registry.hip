@@ -287,6 +287,61 @@ int flush_registrations(lgicp_ctx* ctx) {
   return LGICP_OK;
 }
 
+// The k-d visiting order of every keyframe of the table (level by level, all keyframes together),
+// tiles / boxes / query order, and (derive) covariances, flagged normals and records.  The tables
+// are already on the device; `total` = points of all keyframes, tile_base = their range slots.
+int index_and_derive(lgicp_ctx* ctx, Registry& R, hipStream_t st, const lgicp::RegKf* d_kfs,
+                     const IndexSegDev* d_segs, int n_kf, int total, int tile_base, int depth,
+                     bool any_sort, int max_n, bool derive) {
+  // ---- k-d partition, level by level, all keyframes together -----------------------------------
+  if (total > 0) {
+    const int levels = std::max(depth, any_sort ? 1 : 0);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(ctx, R.d_keys[k].reserve((size_t)total));
+      HIP_TRY(ctx, R.d_ids[k].reserve((size_t)total));
+    }
+    HIP_TRY(ctx, R.d_box.reserve((size_t)6 * tile_base));
+    unsigned* const bmin = R.d_box.p;
+    unsigned* const bmax = R.d_box.p + (size_t)3 * tile_base;
+    int end_bit = 33;
+    while (end_bit < 64 && ((unsigned long long)total >> (end_bit - 32)) != 0) ++end_bit;
+    size_t tmp_bytes = 0;
+    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, R.d_keys[0].p, R.d_keys[1].p,
+                                           R.d_ids[0].p, R.d_ids[1].p, (size_t)total, 0, end_bit, st));
+    HIP_TRY(ctx, R.d_tmp.reserve(tmp_bytes));
+    int cur = 0;
+    hipLaunchKernelGGL(lgicp::kd_init_kernel, dim3(blocks), dim3(256), 0, st, d_kfs, n_kf, total,
+                       R.d_ids[cur].p);
+    for (int level = 0; level < levels; ++level) {
+      HIP_TRY(ctx, hipMemsetAsync(bmin, 0xFF, sizeof(unsigned) * 3 * (size_t)tile_base, st));
+      HIP_TRY(ctx, hipMemsetAsync(bmax, 0x00, sizeof(unsigned) * 3 * (size_t)tile_base, st));
+      hipLaunchKernelGGL(lgicp::kd_box_kernel, dim3(blocks), dim3(256), 0, st, d_kfs, n_kf, total, level,
+                         R.d_ids[cur].p, bmin, bmax);
+      hipLaunchKernelGGL(lgicp::kd_key_kernel, dim3(blocks), dim3(256), 0, st, d_kfs, n_kf, total, level,
+                         R.d_ids[cur].p, bmin, bmax, R.d_keys[0].p);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, rocprim::radix_sort_pairs(R.d_tmp.p, tmp_bytes, R.d_keys[0].p, R.d_keys[1].p,
+                                             R.d_ids[cur].p, R.d_ids[cur ^ 1].p, (size_t)total, 0,
+                                             end_bit, st));
+      cur ^= 1;
+    }
+    hipLaunchKernelGGL(lgicp::kd_order_out_kernel, dim3(blocks), dim3(256), 0, st, d_kfs, n_kf, total,
+                       R.d_ids[cur].p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, launch_index_fill(d_segs, n_kf, max_n, st));
+  }
+  if (!derive || total == 0) return LGICP_OK;
+
+  // ---- what depends on a keyframe alone ----------------------------------------------------------
+  {
+    int bx = std::max(1, std::min(64, (max_n + 255) / 256));
+    hipLaunchKernelGGL(lgicp::derive_kernel, dim3(bx, n_kf), dim3(256), 0, st, d_kfs);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return LGICP_OK;
+}
+
 // Registers `count` clouds: upload, spatial index and (derive) what depends on a keyframe alone.
 // out[i] receives the device view of in[i]; the keyframes of one call share one device block.
 // Everything is enqueued on ctx->stream; nothing is waited for, except that the staging buffer
@@ -402,7 +457,7 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
     Keyframe& kf = out[k];
     kf = Keyframe();
     kf.block = block;
-    kf.n = L.n, kf.n_pad = L.n_pad, kf.n_tiles = L.n_tiles, kf.n_q = L.n_q;
+    kf.n = L.n, kf.n_pad = L.n_pad, kf.n_tiles = L.n_tiles, kf.n_q = L.n_q, kf.nf = L.nf;
     kf.d_xyz = reinterpret_cast<float4*>(base + L.xyz);
     kf.d_nrm = reinterpret_cast<float4*>(base + L.nrm);
     kf.d_order = reinterpret_cast<int*>(base + L.order);
@@ -438,52 +493,11 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
   // both pinned buffers (points, tables) are free for the next call once this event has passed
   HIP_TRY(ctx, hipEventRecord(R.ev_stage, st));
 
-  // ---- k-d partition, level by level, all keyframes together -----------------------------------
-  if (total > 0) {
-    const int levels = std::max(depth, any_sort ? 1 : 0);
-    const unsigned blocks = (unsigned)((total + 255) / 256);
-    for (int k = 0; k < 2; ++k) {
-      HIP_TRY(ctx, R.d_keys[k].reserve((size_t)total));
-      HIP_TRY(ctx, R.d_ids[k].reserve((size_t)total));
-    }
-    HIP_TRY(ctx, R.d_box.reserve((size_t)6 * tile_base));
-    unsigned* const bmin = R.d_box.p;
-    unsigned* const bmax = R.d_box.p + (size_t)3 * tile_base;
-    int end_bit = 33;
-    while (end_bit < 64 && ((unsigned long long)total >> (end_bit - 32)) != 0) ++end_bit;
-    size_t tmp_bytes = 0;
-    HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, R.d_keys[0].p, R.d_keys[1].p,
-                                           R.d_ids[0].p, R.d_ids[1].p, (size_t)total, 0, end_bit, st));
-    HIP_TRY(ctx, R.d_tmp.reserve(tmp_bytes));
-    int cur = 0;
-    hipLaunchKernelGGL(lgicp::kd_init_kernel, dim3(blocks), dim3(256), 0, st, d_kfs, n_kf, total,
-                       R.d_ids[cur].p);
-    for (int level = 0; level < levels; ++level) {
-      HIP_TRY(ctx, hipMemsetAsync(bmin, 0xFF, sizeof(unsigned) * 3 * (size_t)tile_base, st));
-      HIP_TRY(ctx, hipMemsetAsync(bmax, 0x00, sizeof(unsigned) * 3 * (size_t)tile_base, st));
-      hipLaunchKernelGGL(lgicp::kd_box_kernel, dim3(blocks), dim3(256), 0, st, d_kfs, n_kf, total, level,
-                         R.d_ids[cur].p, bmin, bmax);
-      hipLaunchKernelGGL(lgicp::kd_key_kernel, dim3(blocks), dim3(256), 0, st, d_kfs, n_kf, total, level,
-                         R.d_ids[cur].p, bmin, bmax, R.d_keys[0].p);
-      HIP_TRY(ctx, hipGetLastError());
-      HIP_TRY(ctx, rocprim::radix_sort_pairs(R.d_tmp.p, tmp_bytes, R.d_keys[0].p, R.d_keys[1].p,
-                                             R.d_ids[cur].p, R.d_ids[cur ^ 1].p, (size_t)total, 0,
-                                             end_bit, st));
-      cur ^= 1;
-    }
-    hipLaunchKernelGGL(lgicp::kd_order_out_kernel, dim3(blocks), dim3(256), 0, st, d_kfs, n_kf, total,
-                       R.d_ids[cur].p);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, launch_index_fill(d_segs, n_kf, max_n, st));
+  {
+    const int rc = index_and_derive(ctx, R, st, d_kfs, d_segs, n_kf, total, tile_base, depth, any_sort, max_n, derive);
+    if (rc != LGICP_OK) return rc;
   }
   if (!derive || total == 0) return LGICP_OK;
-
-  // ---- what depends on a keyframe alone ----------------------------------------------------------
-  {
-    int bx = std::max(1, std::min(64, (max_n + 255) / 256));
-    hipLaunchKernelGGL(lgicp::derive_kernel, dim3(bx, n_kf), dim3(256), 0, st, d_kfs);
-    HIP_TRY(ctx, hipGetLastError());
-  }
   for (size_t k = 0; k < count; ++k)  // ExtractNormals falls back to ComputeNormals (k = 10)
     if (lay[k].missing)
       HIP_TRY(ctx, launch_normals_knn(out[k].d_xyz, out[k].n, out[k].n_pad, std::min(10, out[k].n),
@@ -518,6 +532,115 @@ int register_keyframes(lgicp_ctx* ctx, const KfInput* in, size_t count, Keyframe
   HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_ids, h_ids, 0));
   HIP_TRY(ctx, launch_normalize_constants(d_clouds, d_ids + first, (int)count, st));
   return LGICP_OK;
+}
+
+// Accumulated clouds as keyframes of their own (see AccEntry): points and normals come from the
+// resident member keyframes through assemble_kernel instead of an upload; everything after that is
+// what registration does.
+int register_accumulated(lgicp_ctx* ctx, Registry& R, hipStream_t st, AccBuild* builds, size_t count) {
+  if (count == 0) return LGICP_OK;
+  const int n_kf = (int)count;
+  size_t n_segs = 0;
+  for (size_t k = 0; k < count; ++k) n_segs += 1 + builds[k].segs.size();
+  // tables: [RegKf x n_kf][IndexSegDev x n_kf][SegmentDev x n_segs]
+  const size_t o_iseg = align256(sizeof(lgicp::RegKf) * count);
+  const size_t o_seg = o_iseg + align256(sizeof(IndexSegDev) * count);
+  const size_t tab_bytes = o_seg + align256(sizeof(SegmentDev) * n_segs);
+  if (R.ev_stage) HIP_TRY(ctx, hipEventSynchronize(R.ev_stage));
+  else HIP_TRY(ctx, hipEventCreateWithFlags(&R.ev_stage, hipEventDisableTiming));
+  HIP_TRY(ctx, pinned_reserve(&R.h_tab, &R.tab_cap, tab_bytes));
+  HIP_TRY(ctx, R.d_tab.reserve(tab_bytes));
+  lgicp::RegKf* h_kfs = reinterpret_cast<lgicp::RegKf*>(R.h_tab);
+  IndexSegDev* h_isegs = reinterpret_cast<IndexSegDev*>(R.h_tab + o_iseg);
+  SegmentDev* h_segs = reinterpret_cast<SegmentDev*>(R.h_tab + o_seg);
+  int pos = 0, tile_base = 0, depth = 0, max_n = 0, max_seg_n = 0;
+  size_t seg_i = 0;
+  for (size_t k = 0; k < count; ++k) {
+    AccBuild& B = builds[k];
+    int n = B.own->n, nf = B.own->nf;
+    for (auto& sg : B.segs) n += sg.first->n, nf += sg.first->nf;
+    if (nf != n) return fail(ctx, LGICP_E_INVALID, "accumulated cloud with non-finite points");
+    const int n_pad = std::max(NN_TILE, round_up(n, NN_TILE));
+    const int n_tiles = (n + SI_TILE - 1) / SI_TILE, n_q = round_up(n, 64);
+    const size_t np = (size_t)std::max(n, 1), t = (size_t)std::max(n_tiles, 1);
+    size_t bytes = 0;
+    auto take = [&](size_t b) {
+      const size_t o = bytes;
+      bytes += align256(b);
+      return o;
+    };
+    const size_t o_xyz = take(sizeof(float4) * (size_t)n_pad), o_nrm = take(sizeof(float4) * np);
+    const size_t o_order = take(sizeof(int) * np), o_sxyz = take(sizeof(float4) * t * SI_TILE);
+    const size_t o_tmin = take(sizeof(float4) * (t + (t + 63) / 64));
+    const size_t o_tmax = take(sizeof(float4) * (t + (t + 63) / 64));
+    const size_t o_qorder = take(sizeof(int) * (size_t)std::max(n_q, 64));
+    const size_t o_cov = take(sizeof(double) * 6 * np), o_rec = take(sizeof(float4) * 2 * np);
+    const size_t o_cnrm = take(sizeof(float4) * np);
+    // freed through the parking list: hipFree would wait for every stream of the device
+    std::shared_ptr<DevBlock> block(new DevBlock, [](DevBlock* b) {
+      park_device_memory(b->p);
+      b->p = nullptr;
+      delete b;
+    });
+    HIP_TRY(ctx, hipMalloc((void**)&block->p, std::max<size_t>(bytes, 256)));
+    char* const base = block->p;
+    Keyframe& kf = B.out->kf;
+    kf = Keyframe();
+    kf.block = block;
+    kf.n = n, kf.n_pad = n_pad, kf.n_tiles = n_tiles, kf.n_q = n_q, kf.nf = nf;
+    kf.d_xyz = reinterpret_cast<float4*>(base + o_xyz);
+    kf.d_nrm = reinterpret_cast<float4*>(base + o_nrm);
+    kf.d_nrm_x = kf.d_nrm;
+    kf.d_order = reinterpret_cast<int*>(base + o_order);
+    kf.d_sxyz = reinterpret_cast<float4*>(base + o_sxyz);
+    kf.d_tmin = reinterpret_cast<float4*>(base + o_tmin);
+    kf.d_tmax = reinterpret_cast<float4*>(base + o_tmax);
+    kf.d_qorder = reinterpret_cast<int*>(base + o_qorder);
+    kf.d_cov = reinterpret_cast<double*>(base + o_cov);
+    kf.d_rec = reinterpret_cast<float4*>(base + o_rec);
+    kf.d_cnrm = reinterpret_cast<float4*>(base + o_cnrm);
+    B.out->bytes = bytes;
+    lgicp::RegKf& g = h_kfs[k];
+    g.xyz = kf.d_xyz, g.nrm = kf.d_nrm, g.cov = kf.d_cov, g.rec = kf.d_rec, g.cnrm = kf.d_cnrm, g.order = kf.d_order;
+    g.pos0 = pos, g.n = n, g.nf = nf, g.tile_base = tile_base;
+    pos += n;
+    tile_base += n_tiles + 1;
+    depth = std::max(depth, kd_depth(nf));
+    max_n = std::max(max_n, n);
+    IndexSegDev& is = h_isegs[k];
+    std::memset(&is, 0, sizeof(is));
+    is.xyz = kf.d_xyz, is.order = kf.d_order, is.sxyz = kf.d_sxyz, is.tmin = kf.d_tmin, is.tmax = kf.d_tmax;
+    is.qorder = kf.d_qorder, is.point_off = 0, is.tile_off = 0, is.n = n, is.last = 1, is.n_q = n_q;
+    // AccumulateScans: the key's own scan, then every neighbour moved into its frame
+    int off = 0;
+    auto seg = [&](const Keyframe* src, const hm::Pose* T) {
+      SegmentDev& sd = h_segs[seg_i++];
+      std::memset(&sd, 0, sizeof(sd));
+      sd.src_xyz = src->d_xyz, sd.src_nrm = src->d_nrm;
+      sd.dst_xyz = kf.d_xyz + off, sd.dst_nrm = kf.d_nrm + off;
+      sd.n = src->n;
+      sd.identity = T ? 0 : 1;
+      if (T)
+        for (int a = 0; a < 3; ++a) {
+          for (int b = 0; b < 3; ++b) sd.T[a * 4 + b] = T->R[a * 3 + b];
+          sd.T[a * 4 + 3] = T->t[a];
+        }
+      max_seg_n = std::max(max_seg_n, src->n);
+      off += src->n;
+    };
+    seg(B.own, nullptr);
+    for (auto& sg : B.segs) seg(sg.first, &sg.second);
+  }
+  const int total = pos;
+  HIP_TRY(ctx, launch_copy16(R.d_tab.p, R.h_tab, tab_bytes, st));
+  HIP_TRY(ctx, hipEventRecord(R.ev_stage, st));
+  const lgicp::RegKf* d_kfs = reinterpret_cast<const lgicp::RegKf*>(R.d_tab.p);
+  const IndexSegDev* d_isegs = reinterpret_cast<const IndexSegDev*>(R.d_tab.p + o_iseg);
+  const SegmentDev* d_segs = reinterpret_cast<const SegmentDev*>(R.d_tab.p + o_seg);
+  HIP_TRY(ctx, launch_assemble(d_segs, (int)n_segs, max_seg_n, st));
+  for (size_t k = 0; k < count; ++k)
+    HIP_TRY(ctx, launch_pad_fill(builds[k].out->kf.d_xyz, builds[k].out->kf.n, builds[k].out->kf.n_pad, st));
+  return index_and_derive(ctx, R, st, d_kfs, d_isegs, n_kf, total, tile_base, depth, false, max_n, true);
 }
 
 }  // namespace lgicp_detail

@@ -105,6 +105,12 @@ struct CloudPlan {  // one distinct point cloud of a batch
   std::vector<std::pair<uint64_t, hm::Pose>> segs;  // appended neighbour keyframes + tf
   int n = 0, n_pad = 0;
   bool need_norm_constants = false;
+  // accumulated and kept on the device from submit to submit (AccEntry): looked up or built when
+  // the batch starts; such a cloud then reads like a registered keyframe
+  bool cacheable = false;
+  std::shared_ptr<AccEntry> entry;
+  // in the arena of the batch (accumulated and not cached)
+  bool in_arena() const { return accumulated && !entry; }
 };
 
 // XCD-aware order of workgroup ids: the dispatcher deals consecutive ids round-robin over the
@@ -304,12 +310,14 @@ void lgicp_destroy(lgicp_ctx* ctx) {
   if (!ctx) return;
   for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->helpers[l].shutdown();
   (void)hipSetDevice(ctx->cfg.device);
+  ParkScope park(ctx);  // whatever is released below through the parking list stays with ctx
   free_parked_device_memory(ctx);
   for (CliqueBuffers*& b : ctx->clique_bufs) {
     clique_buffers_delete(b);
     b = nullptr;
   }
   for (int k = 0; k < lgicp_ctx::MAX_SLOTS; ++k) ctx->slot[k].destroy();
+  ctx->acc_cache.clear();  // parked by their deleters, freed below with everything else parked
   for (auto& kv : ctx->scans) kv.second.free_device();
   ctx->reg.destroy();
   for (int f = 0; f < lgicp_ctx::FEATURE_SETS; ++f) {
@@ -320,6 +328,7 @@ void lgicp_destroy(lgicp_ctx* ctx) {
     for (int l = 0; l < lgicp_ctx::FEATURE_SETS * FEATURE_LANES; ++l) ctx->feature_scratch.get()[l].release();
   if (ctx->sac_lanes)
     for (int l = 0; l < lgicp_ctx::FEATURE_SETS * FEATURE_LANES; ++l) ctx->sac_lanes.get()[l].release();
+  free_parked_device_memory(ctx);
   delete ctx;
 }
 
@@ -572,8 +581,18 @@ int plan_cloud(lgicp_ctx* ctx, BatchPlan& bp, uint64_t key, bool accumulate) {
   cp.n = ctx->scans.at(key).n;
   for (auto& s : cp.segs) cp.n += ctx->scans.at(s.first).n;
   cp.n_pad = std::max(NN_TILE, round_up(cp.n, NN_TILE));
-  if (acc || ctx->cfg.covariance_from_knn) bp.bytes += (size_t)cp.n * (48 + 64) + 1024;  // covariances, records (or flagged normals + compact records)
-  if (acc) {
+  if (acc && !ctx->cfg.covariance_from_knn && ctx->cfg.accumulated_cache_bytes != 1) {
+    // every member finite (the k-d order of the whole needs the count of finite points), and no
+    // normals to be re-estimated over the accumulated cloud for the feature front end
+    const Keyframe& own = ctx->scans.at(key);
+    const bool feature_init = ctx->cfg.init_method == LGICP_INIT_FEATURES ||
+                              ctx->cfg.init_method == LGICP_INIT_TEASERPP;
+    bool ok = own.nf == own.n && !(own.normals_missing && feature_init);
+    for (auto& sg : cp.segs) ok = ok && ctx->scans.at(sg.first).nf == ctx->scans.at(sg.first).n;
+    cp.cacheable = ok;
+  }
+  if ((acc && !cp.cacheable) || ctx->cfg.covariance_from_knn) bp.bytes += (size_t)cp.n * (48 + 64) + 1024;  // covariances, records (or flagged normals + compact records)
+  if (acc && !cp.cacheable) {
     bp.bytes += (size_t)cp.n_pad * 16 + (size_t)cp.n * 32 + 1024;  // xyz + normals (+ estimated)
     // spatial index: tile-ordered points, boxes, visiting order
     bp.bytes += (size_t)cp.n * 23 + (cp.segs.size() + 1) * (SI_TILE * 16 + 64) + 4096;
@@ -619,19 +638,19 @@ void build_cloud_tables(lgicp_ctx* ctx, BatchPlan& bp, Arena& ar, CloudTables* t
   int& max_iseg_n = t->max_iseg_n;
   for (int c = 0; c < n_clouds; ++c) {
     CloudPlan& cp = bp.clouds[c];
-    const Keyframe& kf = ctx->scans.at(cp.key);
+    const Keyframe& kf = cp.entry ? cp.entry->kf : ctx->scans.at(cp.key);
     CloudDev& cd = h_clouds[c];
     std::memset(&cd, 0, sizeof(cd));
     cd.n = cp.n;
     cd.n_pad = cp.n_pad;
-    const bool own_cov = cp.accumulated || cfg.covariance_from_knn;
+    const bool own_cov = cp.in_arena() || cfg.covariance_from_knn;
     cd.cov = own_cov ? ar.take<double>((size_t)cp.n * 6) : kf.d_cov;
     // covariances from normals: flagged normals and 32-byte records; from k-NN: 64-byte records
     cd.compact = cfg.covariance_from_knn ? 0 : 1;
     cd.rec = own_cov ? ar.take<float4>((size_t)cp.n * (cd.compact ? 2 : 4)) : kf.d_rec;
     cd.cnrm = cd.compact ? (own_cov ? ar.take<float4>((size_t)cp.n) : kf.d_cnrm) : nullptr;
     max_cloud_n = std::max(max_cloud_n, cp.n);
-    if (!cp.accumulated) {
+    if (!cp.in_arena()) {
       cd.xyz = kf.d_xyz;
       cd.nrm = kf.d_nrm;
       cd.nrm_x = kf.d_nrm_x;
@@ -747,12 +766,13 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
       if (!feat_ptr.count(c)) {
         // a keyframe on its own keeps its features for later submits; an accumulated cloud is
         // assembled per batch and so are its features
-        Keyframe& kf = ctx->scans.at(bp.clouds[c].key);
-        std::shared_ptr<CloudFeatures> f = bp.clouds[c].accumulated ? nullptr : kf.features;
+        // (an accumulated cloud kept on the device keeps its features with it)
+        Keyframe& kf = bp.clouds[c].entry ? bp.clouds[c].entry->kf : ctx->scans.at(bp.clouds[c].key);
+        std::shared_ptr<CloudFeatures> f = bp.clouds[c].in_arena() ? nullptr : kf.features;
         if (!f) {
           f = std::make_shared<CloudFeatures>();
           todo.push_back(c);
-          if (!bp.clouds[c].accumulated) kf.features = f;
+          if (!bp.clouds[c].in_arena()) kf.features = f;
         }
         feat_ptr[c] = f;
       }
@@ -784,7 +804,8 @@ int initialise_from_features(lgicp_ctx* ctx, const BatchPlan& bp, const std::vec
     if (rc_all.load() != LGICP_OK) {
       // nothing half-made stays behind on a keyframe
       for (int c : todo)
-        if (!bp.clouds[c].accumulated) ctx->scans.at(bp.clouds[c].key).features.reset();
+        if (!bp.clouds[c].in_arena())
+          (bp.clouds[c].entry ? bp.clouds[c].entry->kf : ctx->scans.at(bp.clouds[c].key)).features.reset();
       {
         bool no_text;
         {
@@ -1063,6 +1084,69 @@ hipError_t spin_until(hipEvent_t ev) {
   }
 }
 
+// Accumulated clouds kept on the device (AccEntry, lgicp_config::accumulated_cache_bytes): every
+// cacheable cloud of the submit's plans gets its entry -- found in the context's cache, or built
+// now, once per key, on the stream and with the registration buffers of slot W, and waited for
+// (the cold path: a cloud is built the first time a candidate names it, or again when a neighbour
+// scan has arrived since).  Least recently used entries go when the budget is exceeded; a batch
+// that still works with one keeps it alive until its slot's next batch, and the memory is freed
+// through the parking list.
+int resolve_accumulated(lgicp_ctx* ctx, std::vector<BatchPlan>& plans, BatchSlot* W) {
+  std::map<uint64_t, std::shared_ptr<AccEntry>> fresh;
+  std::vector<AccBuild> builds;
+  {
+    std::lock_guard<std::mutex> lk(ctx->acc_mu);
+    for (BatchPlan& bp : plans)
+      for (CloudPlan& cp : bp.clouds) {
+        if (!cp.cacheable) continue;
+        std::vector<uint64_t> members;
+        for (auto& sg : cp.segs) members.push_back(sg.first);
+        auto it = ctx->acc_cache.find(cp.key);
+        if (it != ctx->acc_cache.end() && it->second->members == members) {
+          cp.entry = it->second;
+          cp.entry->last_use = ++ctx->acc_tick;
+          continue;
+        }
+        auto f = fresh.find(cp.key);
+        if (f != fresh.end()) {  // another part of this submit names the same cloud
+          cp.entry = f->second;
+          continue;
+        }
+        cp.entry = std::make_shared<AccEntry>();
+        cp.entry->members = std::move(members);
+        fresh[cp.key] = cp.entry;
+        AccBuild b;
+        b.own = &ctx->scans.at(cp.key);
+        for (auto& sg : cp.segs) b.segs.emplace_back(&ctx->scans.at(sg.first), sg.second);
+        b.out = cp.entry.get();
+        builds.push_back(std::move(b));
+      }
+  }
+  if (builds.empty()) return LGICP_OK;
+  {
+    const int rc = register_accumulated(ctx, W->acc_reg, W->stream, builds.data(), builds.size());
+    if (rc != LGICP_OK) return rc;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(W->stream));
+  std::lock_guard<std::mutex> lk(ctx->acc_mu);
+  for (auto& f : fresh) {
+    auto it = ctx->acc_cache.find(f.first);
+    if (it != ctx->acc_cache.end()) ctx->acc_bytes -= it->second->bytes;
+    f.second->last_use = ++ctx->acc_tick;
+    ctx->acc_cache[f.first] = f.second;
+    ctx->acc_bytes += f.second->bytes;
+  }
+  const size_t budget = ctx->cfg.accumulated_cache_bytes ? ctx->cfg.accumulated_cache_bytes : ((size_t)32 << 30);
+  while (ctx->acc_bytes > budget && ctx->acc_cache.size() > 1) {
+    auto lru = ctx->acc_cache.begin();
+    for (auto it = ctx->acc_cache.begin(); it != ctx->acc_cache.end(); ++it)
+      if (it->second->last_use < lru->second->last_use) lru = it;
+    ctx->acc_bytes -= lru->second->bytes;
+    ctx->acc_cache.erase(lru);
+  }
+  return LGICP_OK;
+}
+
 int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_candidate* cand,
                    lgicp_result* out, bool explicit_guess) {
   const bool trace_t = std::getenv("LGICP_TRACE") != nullptr;
@@ -1084,6 +1168,12 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   for (auto& p : bp.pairs) pair_bytes += pair_scratch_bytes(ctx->cfg, bp.clouds[p.src_cloud].n);
   HIP_TRY(ctx, W->arena.reserve(bp.bytes + pair_bytes + 4096));
   Arena ar{W};
+
+  // accumulated clouds kept on the device (resolve_accumulated): alive at least until this slot's
+  // next batch (the slot's previous batch has been waited for: what it kept alive may go)
+  W->acc_in_use.clear();
+  for (CloudPlan& cp : bp.clouds)
+    if (cp.entry) W->acc_in_use.push_back(cp.entry);
 
   CloudTables tables;
   build_cloud_tables(ctx, bp, ar, &tables);
@@ -1265,7 +1355,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   // ---- clouds: accumulate, pad, covariances, normalisation constants --------------------------
   HIP_TRY(ctx, launch_assemble(d_segs, (int)h_segs.size(), max_seg_n, st));
   for (int c = 0; c < n_clouds; ++c)
-    if (bp.clouds[c].accumulated)
+    if (bp.clouds[c].in_arena())
       HIP_TRY(ctx, launch_pad_fill(const_cast<float4*>(h_clouds[c].xyz), h_clouds[c].n,
                                    h_clouds[c].n_pad, st));
   HIP_TRY(ctx, launch_index_fill(d_isegs, (int)h_isegs.size(), max_iseg_n, st));
@@ -1749,6 +1839,13 @@ extern "C" int lgicp_submit_stats(lgicp_ctx* ctx, const lgicp_candidate* cand, s
   }
 
   submit_mark("planned");
+  {
+    const int rc = resolve_accumulated(ctx, plans, &ctx->slot[first_slot]);
+    if (rc != LGICP_OK) {  // nothing of the submit runs
+      rc_all = rc;
+      plans.clear();
+    }
+  }
   plans_ready.store(true, std::memory_order_release);
   worker(0);
   submit_mark("own part done");

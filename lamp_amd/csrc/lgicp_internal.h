@@ -46,6 +46,7 @@ struct DevBlock {  // one device allocation shared by the keyframes registered i
 struct Keyframe {
   int n = 0;
   int n_pad = 0;
+  int nf = 0;  // points with finite coordinates
   std::shared_ptr<DevBlock> block;  // owns every d_* array below
   float4* d_xyz = nullptr;  // n_pad
   float4* d_nrm = nullptr;  // n
@@ -154,6 +155,29 @@ struct Registry {
   void destroy();
 };
 
+// An accumulated cloud (IcpLoopComputation::AccumulateScans, IcpLoopComputation.cc:910-947: a
+// keyframe plus its neighbours key +- i moved into its frame) kept on the device with everything a
+// registered keyframe has: scans and poses never change once stored (first wins,
+// IcpLoopComputation.cc:380-385, 400-402), so the cloud is a function of the keys it is made of.
+// The reference rebuilds it, and the kd-tree over it, inside every PerformAlignment.
+struct AccEntry {
+  std::vector<uint64_t> members;  // the neighbours that went in, in AccumulateScans' order
+  Keyframe kf;                    // points, normals, k-d index, covariances, records of the whole
+  size_t bytes = 0;
+  uint64_t last_use = 0;
+};
+// one accumulated cloud to build: the key's own keyframe, then (neighbour, its pose in the key's frame)
+struct AccBuild {
+  const Keyframe* own;
+  std::vector<std::pair<const Keyframe*, hm::Pose>> segs;
+  AccEntry* out;
+};
+// Builds out->kf of every entry on the device (one allocation each, freed through
+// park_device_memory): assemble, pad, k-d index of the whole cloud, covariances / flagged normals /
+// records from the copied normals.  Enqueued on `st` with the buffers of `R`; one caller per R at a
+// time.
+int register_accumulated(lgicp_ctx* ctx, Registry& R, hipStream_t st, AccBuild* builds, size_t count);
+
 }  // namespace lgicp_detail
 using namespace lgicp_detail;
 
@@ -182,6 +206,8 @@ struct BatchSlot {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   lgicp_stats stats;  // what the batch in this slot adds to the context's statistics
+  Registry acc_reg;   // buffers for building accumulated clouds on this slot's stream
+  std::vector<std::shared_ptr<AccEntry>> acc_in_use;  // alive until the slot's next batch begins
 
   hipEvent_t event() {
     if (ev_used == ev_pool.size()) {
@@ -199,6 +225,8 @@ struct BatchSlot {
   }
   void destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
+    acc_in_use.clear();
+    acc_reg.destroy();
     arena.release(), d_params.release(), d_partials.release(), d_counters.release();
     if (h_params) (void)hipHostFree(h_params);
     for (int k = 0; k < 2; ++k)
@@ -332,6 +360,12 @@ struct lgicp_ctx {
   // device and pinned buffers of the TEASER++ clique search: [0] the single-pair entry points (the
   // context's stream), [1 + f] feature set f; created on first use, released by lgicp_destroy
   lgicp_detail::CliqueBuffers* clique_bufs[FEATURE_SETS + 1] = {};
+  // accumulated clouds by key (AccEntry); a submit looks its targets up here, builds the missing
+  // ones on its own stream and keeps what it uses alive until its slot's next batch
+  std::mutex acc_mu;
+  std::unordered_map<uint64_t, std::shared_ptr<lgicp_detail::AccEntry>> acc_cache;
+  size_t acc_bytes = 0;
+  uint64_t acc_tick = 0;
   // outgrown buffers of this context, freed when one of its submits begins with nothing in flight
   std::mutex parked_mu;
   std::vector<void*> parked_dev, parked_pinned;

@@ -105,6 +105,48 @@ def test_one_pair_of_each_configuration_with_knn_covariances(config, solver):
         assert ang < 5e-3 and te < 2e-2
 
 
+def test_accumulated_cloud_cache_changes_nothing():
+    """Base-station parameters accumulate key +- 2 into every target (IcpLoopComputation.cc:910-947).
+    The engine keeps such clouds on the device with a search index of their own once a submit has
+    built them (lgicp_config.accumulated_cache_bytes): the results are those of a context that
+    assembles them afresh in every submit, bit for bit, also when a neighbour scan arrives between
+    two submits and the cloud has to be rebuilt with it."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C2", pairs=48, points=4096, keyframes=16, consecutive_keys=True)
+    keys = sorted(work.keyframes)
+    late = keys[3]                                   # a neighbour of several targets
+
+    def run(cache_bytes, lanes=1):
+        c = capi.Context(init_method=capi.INIT_IDENTITY, accumulated_cache_bytes=cache_bytes)
+        try:
+            first = [k for k in keys if k != late]
+            c.add_keyframes(first, [work.keyframes[k][0] for k in first], [work.keyframes[k][1] for k in first])
+            for k in keys:
+                c.add_pose(k, *work.poses[k])
+            cands = [p for p in work.candidates() if late not in p]
+            outs = [[capi.result_to_dict(r) for r in c.submit(cands)] for _ in range(2)]
+            c.add_keyframe(late, *work.keyframes[late])   # targets next to it now hold one scan more
+            outs += [[capi.result_to_dict(r) for r in c.submit(cands)] for _ in range(2)]
+            return outs
+        finally:
+            c.close()
+
+    cached, fresh = run(0), run(1)
+    for a_list, b_list in zip(cached, fresh):
+        for a, b in zip(a_list, b_list):
+            assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
+            assert np.array_equal(a["T_icp"], b["T_icp"]) and a["fitness"] == b["fitness"]
+            assert np.array_equal(a["information"], b["information"])
+            assert a["n_correspondences"] == b["n_correspondences"]
+    # a submit that finds its clouds cached returns what the submit that built them returned
+    for a, b in zip(cached[0], cached[1]):
+        assert np.array_equal(a["T_icp"], b["T_icp"]) and a["fitness"] == b["fitness"]
+    # the late scan did change some targets (the test would be vacuous otherwise)
+    assert any(not np.array_equal(a["T_icp"], b["T_icp"]) for a, b in zip(cached[1], cached[2]))
+    assert sum(r["status"] == 0 for r in cached[3]) >= 0.8 * len(cached[3])
+
+
 def test_batch_and_slot_independence():
     """A pair's result does not depend on what else is in the submit, on the order of the
     candidates, or on how the submit is cut over the two concurrent batch slots."""
