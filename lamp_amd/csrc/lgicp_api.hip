@@ -350,57 +350,25 @@ namespace {
 struct AllLanes {
   lgicp_ctx* ctx;
   ParkScope park;
-  explicit AllLanes(lgicp_ctx* c) : ctx(c), park(c) {
-    std::unique_lock<std::mutex> lk(ctx->lane_mu);
-    ctx->lane_cv.wait(lk, [&] {
-      for (int l = 0; l < ctx->n_lanes; ++l)
-        if (ctx->lane_busy[l]) return false;
-      return true;
-    });
-    for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->lane_busy[l] = true;
-    free_parked_device_memory(ctx);
-  }
-  ~AllLanes() {
-    {
-      std::lock_guard<std::mutex> lk(ctx->lane_mu);
-      for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->lane_busy[l] = false;
-    }
-    ctx->lane_cv.notify_all();
-  }
+  LaneTable::Grant grant;
+  explicit AllLanes(lgicp_ctx* c)
+      : ctx(c), park(c), grant(c->lanes.acquire_all([c] { free_parked_device_memory(c); })) {}
+  ~AllLanes() { ctx->lanes.release(grant); }
 };
 
 // One lane of the context -- or, when `wide` lanes from lane 0 on are wanted and no submit is in
 // flight at all, those: a caller that is alone on a context with several lanes gets the width a
-// single submit can use, callers that overlap get one lane each.
+// single submit can use, callers that overlap get one lane each.  (Outgrown buffers are freed only
+// when nothing is in flight: they may still be read by what another lane is running.)
 struct OneLane {
   lgicp_ctx* ctx;
   ParkScope park;
-  int lane = 0, held = 1;
-  OneLane(lgicp_ctx* c, int wide) : ctx(c), park(c) {
-    std::unique_lock<std::mutex> lk(ctx->lane_mu);
-    ctx->lane_cv.wait(lk, [&] {
-      for (int l = 0; l < ctx->n_lanes; ++l)
-        if (!ctx->lane_busy[l]) return true;
-      return false;
-    });
-    bool any_busy = false;
-    for (int l = 0; l < ctx->n_lanes; ++l) any_busy = any_busy || ctx->lane_busy[l];
-    // outgrown buffers may still be read by what another lane has in flight
-    if (!any_busy) free_parked_device_memory(ctx);
-    if (!any_busy && wide > 1) {
-      held = std::min(wide, ctx->n_lanes);
-    } else {
-      while (ctx->lane_busy[lane]) ++lane;
-    }
-    for (int l = lane; l < lane + held; ++l) ctx->lane_busy[l] = true;
-  }
-  ~OneLane() {
-    {
-      std::lock_guard<std::mutex> lk(ctx->lane_mu);
-      for (int l = lane; l < lane + held; ++l) ctx->lane_busy[l] = false;
-    }
-    ctx->lane_cv.notify_all();
-  }
+  LaneTable::Grant grant;
+  int lane, held;
+  OneLane(lgicp_ctx* c, int wide)
+      : ctx(c), park(c), grant(c->lanes.acquire_one(wide, [c] { free_parked_device_memory(c); })),
+        lane(grant.lane), held(grant.held) {}
+  ~OneLane() { ctx->lanes.release(grant); }
 };
 
 // caller holds data_mu exclusively
@@ -484,7 +452,7 @@ int lgicp_set_submit_lanes(lgicp_ctx* ctx, int lanes) {
     ++ctx->n_slots;
   }
   for (int l = 0; l < lgicp_ctx::MAX_LANES; ++l) ctx->helpers[l].shutdown();
-  ctx->n_lanes = lanes;
+  ctx->lanes.set_lanes(lanes);
   // (lane 0's helpers also serve a lone submit that is given several lanes)
   for (int l = 0; l < lanes; ++l)
     ctx->helpers[l].start(feature_init ? 0 : std::max(ctx->n_slots / lanes, l == 0 ? ctx->n_wide : 1) - 1, ctx);
@@ -1720,9 +1688,9 @@ extern "C" int lgicp_submit_stats(lgicp_ctx* ctx, const lgicp_candidate* cand, s
   // (a context with a feature-based initialisation has at most two lanes, each with one of the
   // context's two sets of feature buffers and four streams, see lgicp_set_submit_lanes)
   const bool feature_init = cfg.init_method == LGICP_INIT_FEATURES || cfg.init_method == LGICP_INIT_TEASERPP;
-  const bool whole_context = ctx->n_lanes == 1;
+  const bool whole_context = ctx->lanes.lanes() == 1;
   // slots per lane, and the lanes that cover the slots one submit can be spread over
-  const int per_lane = feature_init ? FEATURE_LANES : std::max(1, ctx->n_slots / ctx->n_lanes);
+  const int per_lane = feature_init ? FEATURE_LANES : std::max(1, ctx->n_slots / ctx->lanes.lanes());
   const int wide_lanes = feature_init ? 1 : (ctx->n_wide + per_lane - 1) / per_lane;
   std::unique_ptr<AllLanes> hold_all(whole_context ? new AllLanes(ctx) : nullptr);
   std::unique_ptr<OneLane> hold_one(whole_context ? nullptr : new OneLane(ctx, wide_lanes));

@@ -18,6 +18,7 @@
 
 #include "../../include/lamp_gicp.h"
 #include "host_math.h"
+#include "lane_table.h"
 #include "lgicp_device.h"
 #include "teaser.h"
 
@@ -330,12 +331,9 @@ struct lgicp_ctx {
   // Submits that may run side by side, each on its own share of the slots (lgicp_set_submit_lanes):
   // lane l owns slots [l * n_slots / n_lanes, (l + 1) * n_slots / n_lanes), the calling thread
   // runs the first of them and helpers[l] the others.
-  static constexpr int MAX_LANES = 8;
-  int n_lanes = 1;
+  static constexpr int MAX_LANES = lgicp_detail::LaneTable::MAX_LANES;
+  lgicp_detail::LaneTable lanes;
   SlotThreads helpers[MAX_LANES];
-  std::mutex lane_mu;
-  std::condition_variable lane_cv;
-  bool lane_busy[MAX_LANES] = {};
   // keyframes and poses: submits read them (shared), registration and lgicp_align change them
   mutable std::shared_mutex data_mu;
   // Writers hold this while they wait for and hold data_mu, submits pass through it before they
