@@ -285,6 +285,72 @@ def test_submit_matches_oracle_perform_alignment():
         c.close()
 
 
+def test_submit_with_the_reference_solver_matches_oracle_perform_alignment():
+    """PerformAlignment end to end (IcpLoopComputation.cc:420-648) with the reference's own inner
+    solver on both sides: lgicp_config.solver = LGICP_SOLVER_BFGS against the oracle's BFGS (its
+    sums in the device's order, lo_gicp_params.sum_order), odometry guess, base-station block and
+    robot block.  Same gates, same iteration counts, poses to north_star's tolerance."""
+    from lamp_amd import capi
+    from scipy.spatial.transform import Rotation as Rsc
+    for base, block in ((True, dict()), (False, dict(corr_dist=0.1, max_iterations=5, max_tolerable_fitness=0.4,
+                                                     transform_thresholding=0))):
+        c = capi.Context(capi.default_config(base, init_method=capi.INIT_ODOMETRY, solver=capi.SOLVER_BFGS,
+                                             accumulate_source=0))
+        try:
+            pairs = []
+            for i in range(4):
+                # the robot block's 0.1 m correspondence distance needs a guess that close
+                src, sn, tgt, tn, T = F.make_pair(5000 + 500 * i, 70 + i, rot_deg=2.0, trans=0.2)
+                k_to, k_from = 1000 + 10 * i, 5000 + 10 * i
+                _register(c, k_to, tgt, tn)
+                qq = Rsc.from_matrix(T[:3, :3]).as_quat()
+                _register(c, k_from, src, sn, t=T[:3, 3] + 0.02, q=(qq[3], qq[0], qq[1], qq[2]))
+                pairs.append((k_from, k_to, src, sn, tgt, tn, T))
+            res = c.submit([(p[0], p[1]) for p in pairs])
+            for r, (k_from, k_to, src, sn, tgt, tn, T) in zip(res, pairs):
+                d = capi.result_to_dict(r)
+                qq = Rsc.from_matrix(T[:3, :3]).as_quat()
+                p_from = O.pose_from_quat([qq[3], qq[0], qq[1], qq[2]], T[:3, 3] + 0.02)
+                pose21 = O.pose_between(O.pose_from_quat([1, 0, 0, 0], [0, 0, 0]), p_from)
+                ref = O.perform_alignment(O.base_icp_params(init_method=O.INIT_ODOMETRY, solver=O.SOLVER_BFGS,
+                                                            sum_order=1, **block),
+                                          src, sn, tgt, tn, src, tn, pose21)
+                assert d["status"] == ref["status"], (base, d["status"], ref["status"])
+                assert d["iterations"] == ref["iterations"]
+                ang, te = _rot_err(ref["T_icp"], d["T_icp"])
+                assert ang < 1e-4 and te < 1e-4, (base, ang, te)
+                if ref["status"] == 0:
+                    assert abs(d["fitness"] - ref["fitness"]) <= 1e-5 * ref["fitness"]
+                    assert np.allclose(d["delta_t"], ref["delta_t"], atol=1e-4)
+            assert sum(r.status == 0 for r in res) >= 3
+        finally:
+            c.close()
+
+
+def test_reference_known_answer_with_the_reference_solver():
+    """TestLoopComputation.PerformAlignment (loop_closure/test/test_loop_computation.cc:125-182):
+    corner against the corner shifted by (1, -0.001, 0), the test's perturbed odometry poses, the base
+    block untouched (FEATURES initialisation: SAC-IA, then GICP) -- here with the reference's own
+    optimiser selected on the device.  The reference asserts 1e-3."""
+    from lamp_amd import capi
+    corner, cn = F.generate_corner()
+    moved = corner + np.array([1.0, -0.001, 0.0], np.float32)
+    for solver in (capi.SOLVER_BFGS, capi.SOLVER_GAUSS_NEWTON):
+        c = capi.Context(capi.default_config(True, solver=solver))
+        try:
+            assert c.cfg.init_method == capi.INIT_FEATURES and c.cfg.iterations == 200
+            c.add_keyframe(0, corner, cn)
+            c.add_keyframe(100, moved, cn)
+            c.add_pose(0, (1, 0, 0, 0), (0, 0, 0.1))
+            c.add_pose(100, (1, 0, 0, 0), (-0.9, 0.1, 0))
+            d = capi.result_to_dict(c.submit([(100, 0)])[0])
+            assert d["status"] == 0, d["status"]
+            assert np.allclose(d["delta_t"], [1, -0.001, 0], atol=1e-3), d["delta_t"]
+            assert np.allclose(d["delta_R"], np.eye(3), atol=1e-3)
+        finally:
+            c.close()
+
+
 def test_submit_accumulates_neighbour_scans():
     """AccumulateScans (IcpLoopComputation.cc:910-947): target = key +- 2 neighbours moved into
     the key's frame; normals copied unrotated."""
