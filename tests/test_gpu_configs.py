@@ -133,6 +133,12 @@ def test_accumulated_cloud_cache_changes_nothing():
             c.close()
 
     cached, fresh = run(0), run(1)
+    # a budget of three or four clouds for sixteen targets: entries are evicted and rebuilt all the time
+    tight = run(16 << 20)
+    for a_list, b_list in zip(cached, tight):
+        for a, b in zip(a_list, b_list):
+            assert a["status"] == b["status"] and np.array_equal(a["T_icp"], b["T_icp"])
+            assert a["fitness"] == b["fitness"]
     for a_list, b_list in zip(cached, fresh):
         for a, b in zip(a_list, b_list):
             assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
@@ -145,6 +151,56 @@ def test_accumulated_cloud_cache_changes_nothing():
     # the late scan did change some targets (the test would be vacuous otherwise)
     assert any(not np.array_equal(a["T_icp"], b["T_icp"]) for a, b in zip(cached[1], cached[2]))
     assert sum(r["status"] == 0 for r in cached[3]) >= 0.8 * len(cached[3])
+
+
+@pytest.mark.parametrize("solver", ["gn", "bfgs"])
+def test_accumulated_targets_with_submits_side_by_side(solver):
+    """Several host threads submit the same accumulated targets at once on a fresh context (so
+    that more than one of them finds a cloud missing and builds it): every submit returns what a
+    lone submit on a context without the cache returns, with either inner solver."""
+    import threading
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C2", pairs=64, points=4096, keyframes=16, consecutive_keys=True)
+    sv = capi.SOLVER_BFGS if solver == "bfgs" else capi.SOLVER_GAUSS_NEWTON
+
+    def to_dicts(res):
+        return [capi.result_to_dict(r) for r in res]
+
+    c0 = capi.Context(init_method=capi.INIT_IDENTITY, accumulated_cache_bytes=1, solver=sv)
+    try:
+        work.register(c0)
+        ref = to_dicts(c0.submit(work.candidates()))
+    finally:
+        c0.close()
+    c = capi.Context(init_method=capi.INIT_IDENTITY, solver=sv)
+    try:
+        work.register(c)
+        assert c.set_submit_lanes(4) == 4
+        halves = [work.candidates()[:40], work.candidates()[24:]]       # overlapping target sets
+        got, errors = {}, []
+
+        def submitter(k):
+            try:
+                for rep in range(3):
+                    got[(k, rep)] = to_dicts(c.submit(halves[k % 2]))
+            except Exception as e:       # noqa: BLE001
+                errors.append(e)
+
+        th = [threading.Thread(target=submitter, args=(k,)) for k in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        for (k, rep), res in got.items():
+            want = ref[:40] if k % 2 == 0 else ref[24:]
+            for a, b in zip(res, want):
+                assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
+                assert np.array_equal(a["T_icp"], b["T_icp"]) and a["fitness"] == b["fitness"]
+                assert np.array_equal(a["information"], b["information"])
+    finally:
+        c.close()
 
 
 def test_batch_and_slot_independence():
