@@ -407,6 +407,10 @@ def main(argv=None):
     ev.add_argument("output_dir")
     ev.add_argument("--test-name", default="lamp_amd")
     ev.add_argument("--use-gt-odom", action="store_true")
+    ev.add_argument("--solver", default="gn", choices=["gn", "bfgs"],
+                    help="inner solver: Gauss-Newton (default) or the reference's BFGS (lgicp_config.solver)")
+    ev.add_argument("--robot", action="store_true",
+                    help="the reference's robot parameter block instead of the base station's")
     sy = sub.add_parser("synth", help="write a synthetic data set in the reference's format")
     sy.add_argument("output_dir")
     args = ap.parse_args(argv)
@@ -415,7 +419,9 @@ def main(argv=None):
         return 0
     from . import capi
     data = load_test_data(args.dataset_path)
-    res, fres, info = evaluate(data, use_gt_odom=args.use_gt_odom, init_method=capi.INIT_ODOMETRY)
+    res, fres, info = evaluate(data, use_gt_odom=args.use_gt_odom, init_method=capi.INIT_ODOMETRY,
+                               base_station=not args.robot,
+                               solver=capi.SOLVER_BFGS if args.solver == "bfgs" else capi.SOLVER_GAUSS_NEWTON)
     s = summarize(data, res, fres)
     write_summary(s, args.output_dir, args.test_name)
     print(f"{len(res)} loop closures, {len(fres)} incorrect loop closures, "

@@ -327,6 +327,25 @@ def test_submit_with_the_reference_solver_matches_oracle_perform_alignment():
             c.close()
 
 
+def test_align_with_an_explicit_guess_and_the_reference_solver():
+    """lgicp_align (MultithreadedGICP::align with a guess, gicp.hpp:405-617) under LGICP_SOLVER_BFGS
+    against the oracle's BFGS from the same guess."""
+    from lamp_amd import capi
+    c = capi.Context(init_method=capi.INIT_IDENTITY, solver=capi.SOLVER_BFGS)
+    try:
+        src, sn, tgt, tn, T = F.make_pair(6000, 123, rot_deg=4.0, trans=0.4)
+        guess = np.array(T, np.float32)
+        guess[:3, 3] += np.array([0.05, -0.03, 0.02], np.float32)
+        got = c.align(src, sn, tgt, tn, guess)
+        ref = O.gicp_align(O.base_gicp_params(solver=O.SOLVER_BFGS, sum_order=1), src, sn, tgt, tn, guess)
+        assert got["converged"] and ref["converged"]
+        assert got["iterations"] == ref["iterations"]
+        ang, te = _rot_err(ref["T"], got["T"])
+        assert ang < 1e-4 and te < 1e-4, (ang, te)
+    finally:
+        c.close()
+
+
 def test_reference_known_answer_with_the_reference_solver():
     """TestLoopComputation.PerformAlignment (loop_closure/test/test_loop_computation.cc:125-182):
     corner against the corner shifted by (1, -0.001, 0), the test's perturbed odometry poses, the base

@@ -245,6 +245,41 @@ def test_bfgs_back_end_follows_the_reference_solver(case, block):
     assert abs(par["bit_identical"] - g["gpu_bfgs_vs_oracle_bfgs_parallel_sum_order"]["bit_identical"]) <= 4
 
 
+@pytest.mark.parametrize("case", ["C1", "C2", "C3"])
+def test_gpu_vs_reference_solver_within_the_reference_own_noise(case):
+    """The bound that holds against the reference's solver.  north_star asks for 1e-4 rad /
+    1e-4 m: nine pairs in ten meet the rotation bar and the median pair the translation bar;
+    the tails (rotation up to 2e-4 rad, translation up to 6e-4 m over 128 measured pairs) are
+    the size of the reference's own self-gap (its answer moves by up to a millimetre when the
+    guess moves by a micrometre), so no tighter bound on the maximum can hold against it."""
+    g = _golden()[case]
+    m = measure(case)
+    d = m["gpu_vs_bfgs"]
+    assert d["rot_rad"]["p90"] < 1e-4 and d["rot_rad"]["max"] < 5e-4, d
+    assert d["trans_m"]["p50"] < 1e-4 and d["trans_m"]["max"] < 1e-3, d
+    # the gap is not larger than what the reference does to itself under a 1 um change of guess
+    bs = m["bfgs_self_gap_guess_moved_1um"]
+    assert d["trans_m"]["p50"] <= 3.0 * max(bs["trans_m"]["p50"], 2e-5), (d, bs)
+    assert d["trans_m"]["max"] <= 3.0 * max(bs["trans_m"]["max"], 1e-4), (d, bs)
+    assert d["rot_rad"]["max"] <= 3.0 * max(bs["rot_rad"]["max"], 2e-5), (d, bs)
+    # while the GPU's own answer is stable under the same change
+    gs = m["gpu_self_gap_guess_moved_1um"]
+    assert gs["trans_m"]["p50"] < 1e-6 and gs["trans_m"]["max"] < 1e-4, gs
+    assert gs["rot_rad"]["p50"] < 1e-7 and gs["rot_rad"]["max"] < 1e-4, gs
+    # both minimise the same objective: equal values, and the GPU's answer is the more stationary
+    s = m["stationarity_grad_norm"]
+    assert s["gpu"]["p50"] < 0.1 * s["bfgs"]["p50"], s
+    assert s["gpu"]["max"] < 1e-2, s   # the reference's own gradient tolerance (gicp.hpp:250)
+    assert m["objective_rel_diff_gpu_minus_bfgs"]["max"] < 5e-3, m["objective_rel_diff_gpu_minus_bfgs"]
+    # the limit-cycle exit moves a pose by far less than the reference's noise
+    cyc = m["cycle_exit"]["pose_change_without_it"]
+    if cyc is not None:
+        assert cyc["trans_m"]["max"] < 2e-5 and cyc["rot_rad"]["max"] < 1e-5, cyc
+    # the committed distribution is what this measurement reproduces (same seeds, same code)
+    assert d["trans_m"]["max"] <= 2.0 * g["gpu_vs_bfgs"]["trans_m"]["max"] + 1e-5
+    assert d["rot_rad"]["max"] <= 2.0 * g["gpu_vs_bfgs"]["rot_rad"]["max"] + 1e-6
+
+
 def test_committed_bfgs_distribution_covers_both_blocks():
     g = _golden_bfgs()
     assert sorted(g) == sorted((c, b) for c in ("C1", "C2", "C3", "C5") for b in ("base", "robot"))
