@@ -203,6 +203,38 @@ def test_accumulated_targets_with_submits_side_by_side(solver):
         c.close()
 
 
+@pytest.mark.parametrize("method", ["features", "teaser"])
+def test_feature_initialisation_on_accumulated_targets(method):
+    """Keypoints and descriptors of an accumulated target are those of the whole accumulated
+    cloud (IcpLoopComputation.cc:436-447 runs after AccumulateScans).  With the cloud cached on the
+    device they are computed once and kept beside it: initial alignment and refined pose equal
+    those of a context that assembles the cloud and its features afresh in every submit."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=8, points=4096, keyframes=8, consecutive_keys=True)
+    init = capi.INIT_FEATURES if method == "features" else capi.INIT_TEASERPP
+
+    def run(cache_bytes):
+        c = capi.Context(init_method=init, harris_radius=0.5, transform_thresholding=0,
+                         accumulated_cache_bytes=cache_bytes)
+        try:
+            work.register(c)
+            return [[capi.result_to_dict(r) for r in c.submit(work.candidates())] for _ in range(2)]
+        finally:
+            c.close()
+
+    cached, fresh = run(0), run(1)
+    for a_list, b_list in zip(cached, fresh):
+        for a, b in zip(a_list, b_list):
+            assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
+            assert np.array_equal(a["T_init"], b["T_init"]) and np.array_equal(a["T_icp"], b["T_icp"])
+            assert a["fitness"] == b["fitness"] and a["init_fitness"] == b["init_fitness"]
+    for a, b in zip(cached[0], cached[1]):
+        assert np.array_equal(a["T_init"], b["T_init"]) and np.array_equal(a["T_icp"], b["T_icp"])
+    # the initial alignment did something: it differs from the odometry guess for most pairs
+    assert sum(r["init_fitness"] > 0 for r in cached[0]) >= 4
+
+
 def test_batch_and_slot_independence():
     """A pair's result does not depend on what else is in the submit, on the order of the
     candidates, or on how the submit is cut over the two concurrent batch slots."""
