@@ -239,7 +239,7 @@ def run_steps_in_flight(n_steps, first, depth, submit_step, on_result):
         raise failed[0]
 
 
-def make_config(capi, args, local_rank, slots=0):
+def make_config(capi, args, local_rank, slots=0, stage_timing=False):
     if args.config == "C4":
         cfg = capi.default_config(True, device=local_rank,
                                   init_method=capi.INIT_FEATURES if args.c4_init == "sac" else capi.INIT_TEASERPP,
@@ -254,6 +254,10 @@ def make_config(capi, args, local_rank, slots=0):
         cfg.reserved[2] = 1
     if slots:
         cfg.reserved[7] = slots
+    # per-stage hipEvent times (lgicp_stats nn_ms ...): the events sit between the kernels of every
+    # outer iteration and cost a lone C2 submit 5-7 %, so the timed region runs without them unless
+    # no exclusive phase will measure the stages
+    cfg.stage_timing = 1 if stage_timing else 0
     return cfg
 
 
@@ -344,7 +348,8 @@ def main():
         key_lists.append(keys)
     total_pairs_per_batch = len(works[0].pairs) if strong else len(works[0].pairs) * world
 
-    ctx = capi.Context(make_config(capi, args, local_rank, args.slots))
+    main_stage_timing = bool(args.no_exclusive_phase or args.exhaustive or args.config == "C4")
+    ctx = capi.Context(make_config(capi, args, local_rank, args.slots, stage_timing=main_stage_timing))
     # Steps overlap: the last outer iterations of a batch (a handful of pairs, latency-bound) run
     # beside the full-size launches of the next ones.  A context with a feature-based initialisation
     # (C4) takes two submits at a time.
@@ -541,7 +546,7 @@ def main():
     excl = None
     # (C4: the TEASER++ stage, where its time goes, runs on one stream with only the next group's graph kernels beside it)
     if not args.no_exclusive_phase and rank == 0 and not args.exhaustive and args.config != "C4":
-        c1 = capi.Context(make_config(capi, args, local_rank, slots=1))
+        c1 = capi.Context(make_config(capi, args, local_rank, slots=1, stage_timing=True))
         try:
             for w, keys in zip(works, key_lists):
                 register(c1, w, keys)
@@ -626,8 +631,7 @@ def main():
                 "outer_iterations_mean_rank0": float(np.mean(its)) if its else 0.0,
                 "mean_correspondences_rank0": tgt_pts,
                 "registration_ms_per_keyframe": 1e3 * t_reg / max(len(keys), 1),
-                "stage_ms_last_submit_rank0": {"nn": st.nn_ms, "reduce": st.reduce_ms, "solve": st.solve_ms,
-                                               "prepare": st.cov_ms, "post": st.post_ms, "device_span": st.total_ms},
+                "device_span_ms_last_submit_rank0": st.total_ms,
                 "n_gpus": world if cut_over_ranks else 1,
                 "rccl_ranks": (dist.get_world_size() if (cut_over_ranks and dist is not None) else None),
                 "seed": w.seed,
@@ -638,6 +642,7 @@ def main():
             # the lookup kernel's figures from the same batch on one stream (durations exclusive)
             cfg1 = capi.default_config(True, device=local_rank, init_method=capi.INIT_IDENTITY)
             cfg1.reserved[7] = 1
+            cfg1.stage_timing = 1
             c1 = capi.Context(cfg1)
             try:
                 register(c1, w, keys)
@@ -763,8 +768,13 @@ def main():
                                 if strong else
                                 (f"every one of {world} GPUs runs its own batches, RCCL gather to rank 0"
                                  if world > 1 else "single GPU")),
-                "stage_ms_per_step": {("prepare_and_init" if k == "cov" else k): v / args.steps
-                                      for k, v in stage.items()},
+                "stage_ms_per_step": ({("prepare_and_init" if k == "cov" else k): v / args.steps
+                                       for k, v in stage.items()} if main_stage_timing or not excl else
+                                      {("prepare_and_init" if k == "cov" else k): v / excl["steps"]
+                                       for k, v in excl["stage"].items()}),
+                "stage_ms_source": ("timed region" if main_stage_timing or not excl else
+                                    "exclusive one-stream phase (lgicp_config.stage_timing is off in the "
+                                    "timed region: its events between the kernels cost a lone submit 5-7 %)"),
                 "stage_ms_what": "hipEvent time per stage summed over the parts of a submit: nn = lookups, "
                                  "reduce / solve = linearise-reduce and 6x6 solve (or the BFGS back end's two "
                                  "kernels), prepare_and_init = scan accumulation, index of accumulated clouds, "

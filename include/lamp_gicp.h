@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LGICP_ABI_VERSION 2
+#define LGICP_ABI_VERSION 3
 
 /* call-level error codes */
 enum {
@@ -130,6 +130,11 @@ typedef struct lgicp_config {
                                  recently used first out (0 = 32 GiB, 1 = keep none: every submit
                                  assembles its accumulated clouds afresh, results are the same) */
   int solver;                 /* LGICP_SOLVER_* (0 = Gauss-Newton) */
+  int stage_timing;           /* 1 = time every stage of a submit with events on its streams
+                                 (lgicp_stats nn_ms, reduce_ms, solve_ms, cov_ms, post_ms,
+                                 last_nn_kernel_ms; they stay 0 otherwise).  Off by default: the
+                                 events sit between the kernels of every outer iteration and cost a
+                                 lone submit 5-7 % of its time.  total_ms is always measured. */
   int reserved[8];            /* tuning/diagnostics, 0 = default: [0] queries per lane of the
                                  exhaustive 1-NN kernel (2, 4, 8); [1] its target splits;
                                  [2] 1 = use the exhaustive 1-NN kernel instead of the pruned
@@ -184,8 +189,9 @@ typedef struct lgicp_stats {
   uint64_t outer_iterations;    /* summed over pairs */
   uint64_t nn_launches;         /* launches of the 1-NN kernel */
   double nn_distance_evals;     /* N*M summed over launches and pairs (8 flop each) */
-  double nn_ms, reduce_ms, solve_ms, cov_ms, post_ms, total_ms; /* hipEvent time, last submit */
-  double last_nn_kernel_ms;     /* average duration of one 1-NN launch in the last submit */
+  double nn_ms, reduce_ms, solve_ms, cov_ms, post_ms, total_ms; /* hipEvent time, last submit; all
+                                   but total_ms need lgicp_config::stage_timing */
+  double last_nn_kernel_ms;     /* duration of the last 1-NN launch of the last submit (stage_timing) */
   double last_nn_evals_per_launch;
   double nn_executed_evals;     /* distances the pruned 1-NN kernel actually evaluated, last submit */
   double reduce_points;         /* source points read by the linearise/reduce kernel, summed over

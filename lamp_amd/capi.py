@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblamp_gicp.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 INIT_IDENTITY, INIT_ODOMETRY, INIT_ODOM_ROTATION, INIT_FEATURES, INIT_TEASERPP, INIT_CANDIDATE = range(6)
 COV_POINT2POINT, COV_POINT2PLANE = 0, 1
 SOLVER_GAUSS_NEWTON, SOLVER_BFGS = 0, 1
@@ -40,7 +40,7 @@ class Config(C.Structure):
                 ("harris_threshold", C.c_double), ("harris_suppression", C.c_int),
                 ("harris_radius", C.c_double), ("harris_refine", C.c_int),
                 ("harris_response", C.c_int), ("workspace_bytes", C.c_size_t),
-                ("accumulated_cache_bytes", C.c_size_t), ("solver", C.c_int), ("reserved", C.c_int * 8)]
+                ("accumulated_cache_bytes", C.c_size_t), ("solver", C.c_int), ("stage_timing", C.c_int), ("reserved", C.c_int * 8)]
 
 
 class Candidate(C.Structure):

@@ -447,12 +447,16 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
                                                         PairState* __restrict__ st,
                                                         const int* __restrict__ n_chunks,
                                                         const double* __restrict__ partials,
-                                                        SolveParams sp, int* __restrict__ n_done) {
+                                                        SolveParams sp, int* __restrict__ n_done,
+                                                        int iter, int* __restrict__ ticket) {
   __shared__ SolveLds L;
   const int pair = blockIdx.x;
   PairState& S = st[pair];
-  if (!S.active) return;
   const int lane = threadIdx.x;
+  if (!S.active) {
+    if (lane == 0) iteration_tick(ticket, (int)gridDim.x, n_done, iter);
+    return;
+  }
   // history of the cycle test: one entry per lane, fetched while the slabs are being summed
   const unsigned long long my_hist = S.Thash[lane & 15];
   {
@@ -668,18 +672,19 @@ __global__ __launch_bounds__(64) void gicp_solve_kernel(const PairDev* __restric
     mat4f_mul(Tprev, G, Tf);  // final_transformation_ = previous_ * guess (gicp.hpp:583)
     for (int i = 0; i < 16; ++i) S.Tfinal[i] = Tf[i];
     S.active = 0;
-    // per-pair "left the loop" flag; n_done lives in pinned host memory, the store becomes
-    // visible to the host at the latest when the kernel ends
-    n_done[1 + pair] = 1;
+    // per-pair "left the loop" flag: the iteration it happened in.  n_done lives in pinned host
+    // memory; entry 0 receives the iteration number once every workgroup has got this far
+    __hip_atomic_store(&n_done[1 + pair], iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  iteration_tick(ticket, (int)gridDim.x, n_done, iter);
 }
 
 hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
                              const int* n_chunks, const double* partials, SolveParams sp,
-                             int* n_done, hipStream_t stream) {
+                             int* n_done, int iter, int* ticket, hipStream_t stream) {
   if (n_pairs <= 0) return hipSuccess;
   hipLaunchKernelGGL(gicp_solve_kernel, dim3(n_pairs), dim3(64), 0, stream, pairs, st, n_chunks,
-                     partials, sp, n_done);
+                     partials, sp, n_done, iter, ticket);
   return hipGetLastError();
 }
 

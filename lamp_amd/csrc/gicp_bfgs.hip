@@ -583,11 +583,15 @@ struct Bfgs {
 // convergence test of the outer loop (gicp.hpp:526-541, 564-580).
 __global__ __launch_bounds__(BF_THREADS) void gicp_bfgs_kernel(
     const PairDev* __restrict__ pairs, PairState* __restrict__ st, const int* __restrict__ n_chunks,
-    const double* __restrict__ partials, SolveParams sp, int* __restrict__ n_done) {
+    const double* __restrict__ partials, SolveParams sp, int* __restrict__ n_done, int iter,
+    int* __restrict__ ticket) {
   __shared__ double sums[2][BF_WAVES][BF_NSUM];
   const int pair = blockIdx.x;
   PairState& S = st[pair];
-  if (!S.active) return;
+  if (!S.active) {
+    if (threadIdx.x == 0) iteration_tick(ticket, (int)gridDim.x, n_done, iter);
+    return;
+  }
   const PairDev& P = pairs[pair];
   double mcount = 0;
   {
@@ -660,16 +664,18 @@ __global__ __launch_bounds__(BF_THREADS) void gicp_bfgs_kernel(
     mat4f_mul(Tprev, G, Tf);  // final_transformation_ = previous_ * guess (gicp.hpp:583)
     for (int i = 0; i < 16; ++i) S.Tfinal[i] = Tf[i];
     S.active = 0;
-    n_done[1 + pair] = 1;  // pinned host memory, visible at the latest when the kernel ends
+    // pinned host memory: the iteration in which the pair left the loop
+    __hip_atomic_store(&n_done[1 + pair], iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  iteration_tick(ticket, (int)gridDim.x, n_done, iter);
 }
 
 hipError_t launch_gicp_bfgs(const PairDev* pairs, PairState* st, int n_pairs, const int* n_chunks,
-                            const double* partials, SolveParams sp, int* n_done,
-                            hipStream_t stream) {
+                            const double* partials, SolveParams sp, int* n_done, int iter,
+                            int* ticket, hipStream_t stream) {
   if (n_pairs <= 0) return hipSuccess;
   hipLaunchKernelGGL(gicp_bfgs_kernel, dim3(n_pairs), dim3(BF_THREADS), 0, stream, pairs, st,
-                     n_chunks, partials, sp, n_done);
+                     n_chunks, partials, sp, n_done, iter, ticket);
   return hipGetLastError();
 }
 

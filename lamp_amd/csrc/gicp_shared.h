@@ -92,6 +92,23 @@ static __device__ void apply_state(const double x[6], float T[16]) {
   T[15] = 1.f;
 }
 
+// End of a solve workgroup's part in an outer iteration, called by one thread of every workgroup of
+// the launch as its last action.  The last workgroup to arrive publishes the iteration number in
+// host memory: the host then knows that the solve kernel of that iteration is through, without an
+// event between the kernels of the stream.  `ticket` counts arrivals and is back at zero when the
+// launch ends.  A thread's earlier stores to host memory (its pair's flag) have left the compute
+// unit before it takes its ticket, nothing is written back from the caches for it: should a flag
+// become visible to the host after the number all the same, the host takes the pair for active one
+// iteration longer, which changes no result (what a pair does is decided by its state on the
+// device).
+__device__ __forceinline__ void iteration_tick(int* ticket, int n_blocks, int* host_iter, int iter) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (atomicAdd(ticket, 1) == n_blocks - 1) {
+    atomicExch(ticket, 0);
+    __hip_atomic_store(host_iter, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 static __device__ void mat4f_mul(const float a[16], const float b[16], float out[16]) {
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {

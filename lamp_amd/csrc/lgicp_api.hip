@@ -1126,6 +1126,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   };
 
   const lgicp_config& cfg = ctx->cfg;
+  const bool stage_events = cfg.stage_timing != 0 || trace_t;  // events between the kernels
   hipStream_t st = W->stream;
   const int n_pairs = (int)bp.pairs.size();
   const int n_clouds = (int)bp.clouds.size();
@@ -1309,8 +1310,10 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   int4* const d_bmap_red = reinterpret_cast<int4*>(dpar + o_red);
   int4* const d_bmap_nn = reinterpret_cast<int4*>(dpar + o_nn);
   HIP_TRY(ctx, W->d_partials.reserve((size_t)n_pairs * RED_MAX_CHUNKS * NSTAT));
-  HIP_TRY(ctx, W->d_counters.reserve(NN_COUNTER_SLOTS));
-  HIP_TRY(ctx, hipMemsetAsync(W->d_counters.p, 0, sizeof(unsigned long long) * NN_COUNTER_SLOTS, st));
+  // the entry after the lookup counters is the solve kernels' arrival ticket (zero between launches)
+  HIP_TRY(ctx, W->d_counters.reserve(NN_COUNTER_SLOTS + 1));
+  HIP_TRY(ctx, hipMemsetAsync(W->d_counters.p, 0, sizeof(unsigned long long) * (NN_COUNTER_SLOTS + 1), st));
+  int* const d_ticket = reinterpret_cast<int*>(W->d_counters.p + NN_COUNTER_SLOTS);
   // the staging buffer is rewritten only by the next batch of this slot, which starts after this
   // batch's last synchronisation
   HIP_TRY(ctx, launch_copy16(dpar, W->h_params, used_bytes, st));
@@ -1364,7 +1367,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   for (int p = 0; p < n_pairs; ++p)
     if (!h_state[p].active && h_pairs[p].cert)
       HIP_TRY(ctx, hipMemsetAsync(h_pairs[p].cert, 0, sizeof(float4) * (size_t)h_pairs[p].n_src, st));
-  HIP_TRY(ctx, hipEventRecord(ev_prep, st));
+  if (stage_events) HIP_TRY(ctx, hipEventRecord(ev_prep, st));
 
   // ---- GICP outer loop -----------------------------------------------------------------------
   SolveParams sp;
@@ -1376,7 +1379,10 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   sp.cycle_exit = (cfg.reserved[5] & 2) ? 0 : 1;
   sp.pad = 0;
   // "Left the loop" flags, one per pair, raised by the solve kernel straight in pinned host memory
-  // (entry 0 is unused): no copy and no second stream between the device and the host's view
+  // (the number of the iteration it happened in); entry 0 is the number of the last iteration whose
+  // solve kernel has finished altogether.  No copy, no event and no second stream between the
+  // device and the host's view: an event recorded between two kernels costs the stream about as
+  // much as a straggler's lookup.
   int* const h_live = W->h_done;
   std::memset(h_live, 0, sizeof(int) * ((size_t)n_pairs + 1));
   int* d_done = nullptr;
@@ -1388,6 +1394,8 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   if (cfg.reserved[4] > 0)  // diagnostics only: a smaller cap drops correspondences
     nn_cap = 1e-6f * (float)cfg.reserved[4] * (float)cfg.reserved[4];
   bool have_matches = false;  // a previous pass has filled PairDev::keys: the next one may seed
+  const bool lagged = !ctx->nn_exhaustive && !(cfg.reserved[5] & 1);
+  int n_enqueued = 0;
   auto nn_pass = [&](bool final_pass) -> hipError_t {
     const bool seed = have_matches && cfg.reserved[6] != 1;
     have_matches = true;
@@ -1445,52 +1453,66 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   // "done" flags of iteration i are looked at, so the device never waits for the round trip.
   // Pairs that have left the loop are skipped by the kernels themselves (PairState::active);
   // the block maps only follow, two iterations late, to keep the grids small.
-  hipEvent_t flag_ev[2] = {nullptr, nullptr};  // end of the solve kernel of an iteration
-  auto enqueue_iteration = [&](int slot) -> int {
-    hipEvent_t a = W->event(), b = W->event(), c = W->event(), d = W->event();
-    HIP_TRY(ctx, hipEventRecord(a, st));
+  auto enqueue_iteration = [&]() -> int {
+    hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+    if (stage_events) a = W->event(), b = W->event(), c = W->event(), d = W->event();
+    const int iter = ++n_enqueued;
+    if (stage_events) HIP_TRY(ctx, hipEventRecord(a, st));
     HIP_TRY(ctx, nn_pass(false));
-    HIP_TRY(ctx, hipEventRecord(b, st));
+    if (stage_events) HIP_TRY(ctx, hipEventRecord(b, st));
     if (cfg.solver == LGICP_SOLVER_BFGS) {
       HIP_TRY(ctx, launch_bfgs_prepare(d_clouds, d_pairs, d_state,
                                        d_bmap_red, (int)h_bmap_red.size(), sp.corr_dist2,
                                        W->d_partials.p, !cfg.covariance_from_knn, st));
-      HIP_TRY(ctx, hipEventRecord(c, st));
+      if (stage_events) HIP_TRY(ctx, hipEventRecord(c, st));
       HIP_TRY(ctx, launch_gicp_bfgs(d_pairs, d_state, n_pairs, d_ints,
-                                    W->d_partials.p, sp, d_done, st));
+                                    W->d_partials.p, sp, d_done, iter, d_ticket, st));
     } else {
       HIP_TRY(ctx, launch_gicp_reduce(d_clouds, d_pairs, d_state,
                                       d_bmap_red, (int)h_bmap_red.size(), sp.corr_dist2,
                                       W->d_partials.p, !cfg.covariance_from_knn, st));
-      HIP_TRY(ctx, hipEventRecord(c, st));
+      if (stage_events) HIP_TRY(ctx, hipEventRecord(c, st));
       HIP_TRY(ctx, launch_gicp_solve(d_pairs, d_state, n_pairs, d_ints,
-                                     W->d_partials.p, sp, d_done, st));
+                                     W->d_partials.p, sp, d_done, iter, d_ticket, st));
     }
-    HIP_TRY(ctx, hipEventRecord(d, st));
-    // once this event has passed, every flag of this iteration is visible to the host (a
-    // later solve kernel that is already running can only add flags, never take one back)
-    flag_ev[slot] = d;
-    nn_ev.emplace_back(a, b);
-    red_ev.emplace_back(b, c);
-    sol_ev.emplace_back(c, d);
+    if (stage_events) {
+      HIP_TRY(ctx, hipEventRecord(d, st));
+      nn_ev.emplace_back(a, b);
+      red_ev.emplace_back(b, c);
+      sol_ev.emplace_back(c, d);
+    }
     return LGICP_OK;
   };
+  // Waits until the solve kernel of iteration k has finished (every flag of iterations <= k is then
+  // visible; the solve kernel of a later iteration that is already running can only add flags).
+  // The stream is looked at now and then: a launch that failed would never report.
+  auto wait_iteration = [&](int k) -> hipError_t {
+    const volatile int* const it = h_live;
+    for (unsigned spins = 1;; ++spins) {
+      if (it[0] >= k) return hipSuccess;
+      if ((spins & 1023u) == 0) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return it[0] >= k ? hipSuccess : hipErrorUnknown;
+        if (e != hipErrorNotReady) return e;
+      }
+      __builtin_ia32_pause();
+    }
+  };
   const int n_active0 = (int)active.size();
-  const bool lagged = !ctx->nn_exhaustive && !(cfg.reserved[5] & 1);
   if (!active.empty()) {
-    int rc = enqueue_iteration(0);
+    int rc = enqueue_iteration();
     if (rc != LGICP_OK) return rc;
     outer = 1;
     for (;;) {
-      const int prev = (outer - 1) & 1;
       bool enqueued = false;
       if (lagged && outer < cfg.iterations + 1) {
-        rc = enqueue_iteration(outer & 1);
+        rc = enqueue_iteration();
         if (rc != LGICP_OK) return rc;
         enqueued = true;
       }
-      HIP_TRY(ctx, spin_until(flag_ev[prev]));
+      HIP_TRY(ctx, wait_iteration(outer));  // the iteration before the one just enqueued
       const volatile int* flags = h_live;
+      // (a flag of the iteration that is running now may be up already)
       int n_flagged = 0;
       for (int p = 0; p < n_pairs; ++p) n_flagged += flags[1 + p] != 0;
       const bool all_done = n_flagged >= n_active0;
@@ -1505,7 +1527,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
         for (int p = 0; p < n_pairs; ++p)
           if (h_state[p].active && !flags[1 + p]) active.push_back(p);
         // A staging buffer is reused two uploads later; each upload is followed in the stream
-        // by the next iteration's flag event, which the host has waited for by then.  Small
+        // by the next iteration's solve kernel, which the host has waited for by then.  Small
         // changes are not worth a copy: blocks of finished pairs exit at once anyway.
         if (!active.empty() && active.size() * 8 <= mapped_active * 7) {
           build_maps(active);
@@ -1515,7 +1537,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
         }
       }
       if (!enqueued) {
-        rc = enqueue_iteration(outer & 1);
+        rc = enqueue_iteration();
         if (rc != LGICP_OK) return rc;
         ++outer;
       }
@@ -1525,9 +1547,9 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
 
   // ---- final pass: fitness + correspondences + Ap ----------------------------------------------
   hipEvent_t ev_post0 = W->event(), ev_post1 = W->event(), ev_post2 = W->event();
-  HIP_TRY(ctx, hipEventRecord(ev_post0, st));
+  if (stage_events) HIP_TRY(ctx, hipEventRecord(ev_post0, st));
   HIP_TRY(ctx, nn_pass(true));
-  HIP_TRY(ctx, hipEventRecord(ev_post1, st));
+  if (stage_events) HIP_TRY(ctx, hipEventRecord(ev_post1, st));
   HIP_TRY(ctx, launch_post_reduce(d_clouds, d_pairs, d_state,
                                   d_bmap_red_all, n_all_red, W->d_partials.p,
                                   cfg.covariance_method == LGICP_COV_POINT2POINT &&
@@ -1587,20 +1609,24 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     }
     fprintf(stderr, "%s\n", line.c_str());
   }
-  const double nn_loop_ms = sum_ms(nn_ev);
-  (void)hipEventElapsedTime(&ms, ev_post0, ev_post1);
-  const double nn_final_ms = ms;
-  S.nn_ms += nn_loop_ms + nn_final_ms;
-  S.reduce_ms += sum_ms(red_ev);
-  S.solve_ms += sum_ms(sol_ev);
-  (void)hipEventElapsedTime(&ms, ev_begin, ev_prep);
-  S.cov_ms += ms;
-  (void)hipEventElapsedTime(&ms, ev_post1, ev_post2);
-  S.post_ms += ms;
+  // per-stage times only with lgicp_config::stage_timing (the events they need sit between the
+  // kernels of every iteration)
+  double nn_final_ms = 0;
+  if (stage_events) {
+    (void)hipEventElapsedTime(&ms, ev_post0, ev_post1);
+    nn_final_ms = ms;
+    S.nn_ms += sum_ms(nn_ev) + nn_final_ms;
+    S.reduce_ms += sum_ms(red_ev);
+    S.solve_ms += sum_ms(sol_ev);
+    (void)hipEventElapsedTime(&ms, ev_begin, ev_prep);
+    S.cov_ms += ms;
+    (void)hipEventElapsedTime(&ms, ev_post1, ev_post2);
+    S.post_ms += ms;
+  }
   (void)hipEventElapsedTime(&ms, ev_begin, ev_post2);
   S.total_ms += ms;
-  S.nn_launches += (uint64_t)nn_ev.size() + 1;
-  S.reduce_launches += (uint64_t)red_ev.size();
+  S.nn_launches += (uint64_t)n_enqueued + 1;
+  S.reduce_launches += (uint64_t)n_enqueued;
   // the final pass always covers every pair of the batch: it is the launch the roofline uses
   S.last_nn_kernel_ms = nn_final_ms;
   S.last_nn_evals_per_launch = evals_per_pass;

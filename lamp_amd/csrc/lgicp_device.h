@@ -214,9 +214,12 @@ hipError_t launch_keys_unpack(const nnkey_t* keys, int n, int32_t* idx, float* d
 hipError_t launch_gicp_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
                               const int4* bmap, int n_blocks, double corr_dist2, double* partials,
                               bool compact, hipStream_t stream);
+// n_done: pinned host memory, 1 + n_pairs ints: entry 1 + p receives `iter` (>= 1) when pair p
+// leaves the loop, entry 0 receives `iter` when every workgroup of the launch has finished;
+// ticket: one int of device memory that is zero between launches
 hipError_t launch_gicp_solve(const PairDev* pairs, PairState* st, int n_pairs,
                              const int* n_chunks, const double* partials, SolveParams sp,
-                             int* n_done, hipStream_t stream);
+                             int* n_done, int iter, int* ticket, hipStream_t stream);
 // BFGS back end (gicp_bfgs.hip): records + correspondence counts of one outer iteration (same block
 // map as launch_gicp_reduce; counts land in partials[(pair, chunk)][0]), then the inner solve,
 // applyState and the convergence test, one workgroup per pair
@@ -224,8 +227,8 @@ hipError_t launch_bfgs_prepare(const CloudDev* clouds, const PairDev* pairs, con
                                const int4* bmap, int n_blocks, double corr_dist2, double* partials,
                                bool compact, hipStream_t stream);
 hipError_t launch_gicp_bfgs(const PairDev* pairs, PairState* st, int n_pairs, const int* n_chunks,
-                            const double* partials, SolveParams sp, int* n_done,
-                            hipStream_t stream);
+                            const double* partials, SolveParams sp, int* n_done, int iter,
+                            int* ticket, hipStream_t stream);
 hipError_t launch_post_reduce(const CloudDev* clouds, const PairDev* pairs, const PairState* st,
                               const int4* bmap, int n_blocks, double* partials, bool point2point,
                               hipStream_t stream);

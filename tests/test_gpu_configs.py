@@ -235,6 +235,33 @@ def test_feature_initialisation_on_accumulated_targets(method):
     assert sum(r["init_fitness"] > 0 for r in cached[0]) >= 4
 
 
+def test_stage_timing_is_optional_and_changes_nothing():
+    """lgicp_config.stage_timing puts events between the kernels of every outer iteration to fill the
+    per-stage times of lgicp_stats; without it only the device span of the submit is measured.
+    The results are the same bits."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C2", pairs=32, points=4096, keyframes=16)
+    outs, stats = [], []
+    for timing in (0, 1):
+        c = capi.Context(init_method=capi.INIT_IDENTITY, stage_timing=timing)
+        try:
+            work.register(c)
+            res, st = c.submit_packed_stats(c.pack_candidates(work.candidates()))
+            outs.append([capi.result_to_dict(res[k]) for k in range(len(work.pairs))])
+            stats.append(st)
+        finally:
+            c.close()
+    for a, b in zip(*outs):
+        assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
+        assert np.array_equal(a["T_icp"], b["T_icp"]) and a["fitness"] == b["fitness"]
+        assert np.array_equal(a["information"], b["information"])
+    assert stats[0].nn_ms == 0 and stats[0].reduce_ms == 0 and stats[0].solve_ms == 0
+    assert stats[0].total_ms > 0 and stats[0].nn_launches == stats[1].nn_launches > 0
+    assert stats[1].nn_ms > 0 and stats[1].reduce_ms > 0 and stats[1].solve_ms > 0
+    assert stats[1].nn_ms + stats[1].reduce_ms + stats[1].solve_ms <= 4.0 * stats[1].total_ms   # four parts side by side
+
+
 def test_batch_and_slot_independence():
     """A pair's result does not depend on what else is in the submit, on the order of the
     candidates, or on how the submit is cut over the two concurrent batch slots."""

@@ -822,8 +822,9 @@ def test_submit_exhaustive_and_pruned_agree():
 
 def test_lookup_certificates_change_nothing():
     """From the second lookup pass on, queries whose match is provably unchanged are answered
-    without a search.  With the certificates switched off (reserved[6] = 2), and with the
-    exhaustive kernel, a batch must produce the same bits in every result field - including
+    without a search.  With the certificates switched off (reserved[6] = 2), with the exhaustive
+    kernel, and with the host waiting for every outer iteration before it enqueues the next, a
+    batch must produce the same bits in every result field - including
     pairs with duplicated targets, points far from everything, partial overlap and a pair that
     never enters the loop."""
     from lamp_amd import capi
@@ -841,9 +842,10 @@ def test_lookup_certificates_change_nothing():
     tiny = rng.normal(size=(5, 3)).astype(np.float32)    # fewer points than k_correspondences
     tiny_n = np.tile(np.float32([0, 0, 1]), (5, 1))
     outs = []
-    for mode in ((0, 0), (0, 2), (1, 0)):
+    # (exhaustive kernel, certificates off, host round trip after every outer iteration)
+    for mode in ((0, 0, 0), (0, 2, 0), (1, 0, 0), (0, 0, 1)):
         res = [0] * 8
-        res[2], res[6] = mode
+        res[2], res[6], res[5] = mode
         c = capi.Context(init_method=capi.INIT_IDENTITY, reserved=(capi.C.c_int * 8)(*res))
         try:
             for i, (src, sn, tgt, tn) in enumerate(clouds):

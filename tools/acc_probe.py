@@ -12,7 +12,8 @@ from lamp_amd.workload import Workload  # noqa: E402
 
 work = Workload("C2", consecutive_keys=True)
 for cache in (0, 1):
-    cfg = capi.default_config(True, init_method=capi.INIT_IDENTITY, accumulated_cache_bytes=cache)
+    cfg = capi.default_config(True, init_method=capi.INIT_IDENTITY, accumulated_cache_bytes=cache,
+                              stage_timing=1)
     if len(sys.argv) > 1:
         cfg.reserved[7] = int(sys.argv[1])
     ctx = capi.Context(cfg)

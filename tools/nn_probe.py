@@ -31,7 +31,7 @@ def main():
     n_pairs = kw.pop("pairs", 256)
     inner = kw.pop("inner", 50)
     wl = workload.Workload("C2", pairs=n_pairs)
-    c = capi.Context(init_method=capi.INIT_IDENTITY, iterations=iters, optimizer_iterations=inner, reserved=(capi.C.c_int * 8)(*res))
+    c = capi.Context(init_method=capi.INIT_IDENTITY, iterations=iters, optimizer_iterations=inner, stage_timing=1, reserved=(capi.C.c_int * 8)(*res))
     wl.register(c)
     packed = c.pack_candidates(wl.candidates())
     reps = kw.pop("reps", 4)

@@ -9,7 +9,7 @@ if os.environ.get("LGICP_LIB"):
 from lamp_amd.workload import Workload
 
 work = Workload("C2")
-cfg = capi.default_config(True, init_method=capi.INIT_IDENTITY)
+cfg = capi.default_config(True, init_method=capi.INIT_IDENTITY, stage_timing=1)
 cfg.reserved[7] = 1
 c = capi.Context(cfg)
 work.register(c)
