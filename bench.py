@@ -354,8 +354,6 @@ def main():
     # beside the full-size launches of the next ones.  A context with a feature-based initialisation
     # (C4) takes two submits at a time.
     in_flight = args.in_flight or (1 if args.slots == 1 else (2 if args.config == "C4" else 6))
-    if in_flight > 1:
-        in_flight = ctx.set_submit_lanes(in_flight)
 
     def register(c, w, keys):
         t0 = time.perf_counter()
@@ -369,9 +367,7 @@ def main():
     for w, keys in zip(works, key_lists):     # keyframes + poses resident in HBM before timing
         reg_s += register(ctx, w, keys)
         reg_kf += len(keys)
-    # one set of candidate / result arrays per submit in flight: step i uses set i mod in_flight
-    packed_sets = [[ctx.pack_candidates(c) for c in cand_lists] for _ in range(in_flight)]
-    packed = packed_sets[0]
+    packed = [ctx.pack_candidates(c) for c in cand_lists]
     progress(f"{reg_kf} keyframes registered in {reg_s:.3f} s")
 
     gatherer = None
@@ -485,16 +481,21 @@ def main():
         progress(f"warm-up {i + 1}/{args.warmup}")
     serial = ser_acc = None
     if in_flight > 1:
-        # every set of arrays and every lane's buffers sized before the timed region; and, for the
-        # record, the same steps one at a time (each submit on one lane's share of the context)
-        collect_overlapped(2 * in_flight, 0, in_flight)
-        n_ser = max(n_batches, min(args.steps, 8))
+        # What a LAMP node gets: one blocking submit per tick on a context as lgicp_create leaves
+        # it (one lane).  Measured first; the lanes for the steps in flight are set up afterwards.
+        n_ser = max(2 * n_batches, min(args.steps, 8))
         barrier()
         t_ser = time.perf_counter()
         ser_acc, _, _ = collect(ctx, n_ser, 0)
         ser_acc["steps"] = n_ser
         barrier()
         serial = (time.perf_counter() - t_ser) / n_ser
+        in_flight = ctx.set_submit_lanes(in_flight)
+    # one set of candidate / result arrays per submit in flight: step i uses set i mod in_flight
+    packed_sets = [packed] + [[ctx.pack_candidates(c) for c in cand_lists] for _ in range(in_flight - 1)]
+    if in_flight > 1:
+        # every set of arrays and every lane's buffers sized before the timed region
+        collect_overlapped(2 * in_flight, 0, in_flight)
     barrier()
     t0 = time.perf_counter()
     if in_flight > 1:
@@ -784,8 +785,9 @@ def main():
                 "one_submit_at_a_time": (None if serial is None else
                                          {"ms_per_step": 1e3 * serial,
                                           "value": total_pairs_per_batch / serial,
-                                          "what": "the same steps submitted one after the other (each on "
-                                                  "one lane's share of the context's streams)"}),
+                                          "what": "the same steps submitted one after the other on the "
+                                                  "context as lgicp_create leaves it (one lane, four parts "
+                                                  "of a submit side by side), before lgicp_set_submit_lanes"}),
                 "registration": {"keyframes": reg_kf, "seconds": reg_s,
                                  "what": "lgicp_add_keyframes + lgicp_wait_registered per batch: upload, "
                                          "k-d index, covariances, records, NormalizePCloud constants"},

@@ -1422,6 +1422,7 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   // single copy (the reduce map's region is directly followed by the 1-NN map's).
   const size_t red_region = o_nn - o_red;
   int stage_k = 0;
+  int stage_after[2] = {-1, -1};  // the loop launch a staging buffer's last copy was enqueued behind
   auto upload_maps = [&]() -> int {
     const size_t bytes = red_region + sizeof(int4) * h_bmap_nn.size();
     const int k = stage_k;
@@ -1442,13 +1443,14 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
   };
   if (n_inactive0) {
     build_maps(active);
+    stage_after[stage_k] = 0;
     const int rc = upload_maps();
     if (rc != LGICP_OK) return rc;
   }
   size_t mapped_active = active.size();
   std::vector<std::pair<hipEvent_t, hipEvent_t>> nn_ev, red_ev, sol_ev;
   std::vector<int> h_flags((size_t)n_pairs + 1, 0);
-  int outer = 0, done_seen = 0;
+  int done_seen = 0;
   // The host stays one iteration behind the device: iteration i+1 is enqueued before the
   // "done" flags of iteration i are looked at, so the device never waits for the round trip.
   // Pairs that have left the loop are skipped by the kernels themselves (PairState::active);
@@ -1499,26 +1501,27 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     }
   };
   const int n_active0 = (int)active.size();
+  // launches of the loop: the kernels enforce the iteration limit themselves, one more launch finds
+  // every pair stopped
+  const int max_launches = cfg.iterations + 1;
+  // The host stays one iteration behind the device: iteration i + 1 is enqueued before the flags
+  // of iteration i are looked at (two or three ahead measured no faster: the host keeps up).
+  const int ahead = lagged ? 1 : 0;
+  int completed = 0;  // iterations whose solve kernel is known to be through
   if (!active.empty()) {
-    int rc = enqueue_iteration();
-    if (rc != LGICP_OK) return rc;
-    outer = 1;
     for (;;) {
-      bool enqueued = false;
-      if (lagged && outer < cfg.iterations + 1) {
-        rc = enqueue_iteration();
+      while (n_enqueued < std::min(completed + 1 + ahead, max_launches)) {
+        const int rc = enqueue_iteration();
         if (rc != LGICP_OK) return rc;
-        enqueued = true;
       }
-      HIP_TRY(ctx, wait_iteration(outer));  // the iteration before the one just enqueued
+      HIP_TRY(ctx, wait_iteration(completed + 1));
+      ++completed;
       const volatile int* flags = h_live;
-      // (a flag of the iteration that is running now may be up already)
+      // (a flag of an iteration that is running now may be up already)
       int n_flagged = 0;
       for (int p = 0; p < n_pairs; ++p) n_flagged += flags[1 + p] != 0;
-      const bool all_done = n_flagged >= n_active0;
-      if (enqueued) ++outer;
-      if (all_done || outer >= cfg.iterations + 1) {
-        if (enqueued) HIP_TRY(ctx, hipStreamSynchronize(st));  // kernels found nothing to do
+      if (n_flagged >= n_active0 || completed >= max_launches) {
+        if (n_enqueued > completed) HIP_TRY(ctx, hipStreamSynchronize(st));  // kernels found nothing to do
         break;
       }
       if (n_flagged != done_seen) {
@@ -1526,20 +1529,16 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
         active.clear();
         for (int p = 0; p < n_pairs; ++p)
           if (h_state[p].active && !flags[1 + p]) active.push_back(p);
-        // A staging buffer is reused two uploads later; each upload is followed in the stream
-        // by the next iteration's solve kernel, which the host has waited for by then.  Small
-        // changes are not worth a copy: blocks of finished pairs exit at once anyway.
-        if (!active.empty() && active.size() * 8 <= mapped_active * 7) {
+        // Small changes are not worth a copy: blocks of finished pairs exit at once anyway.  A
+        // staging buffer is reused two uploads later: only once the iteration enqueued behind its
+        // copy is through.
+        if (!active.empty() && active.size() * 8 <= mapped_active * 7 && completed > stage_after[stage_k]) {
           build_maps(active);
-          rc = upload_maps();
+          stage_after[stage_k] = n_enqueued;
+          const int rc = upload_maps();
           if (rc != LGICP_OK) return rc;
           mapped_active = active.size();
         }
-      }
-      if (!enqueued) {
-        rc = enqueue_iteration();
-        if (rc != LGICP_OK) return rc;
-        ++outer;
       }
     }
   }
