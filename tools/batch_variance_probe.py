@@ -17,6 +17,7 @@ KEY_STRIDE = 100000
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 cfg = capi.default_config(True, init_method=capi.INIT_IDENTITY)
 cfg.reserved[5] = int(os.environ.get("PROBE_R5", "0"))      # loop variants (lamp_gicp.h)
+cfg.reserved[7] = int(os.environ.get("PROBE_SLOTS", "0"))   # parts of a submit side by side
 ctx = capi.Context(cfg)
 packed, its = [], []
 for b in range(4):
