@@ -10,7 +10,7 @@
 // The residual res = Theta*(p,1) - q is linear in the 12 entries of Theta = [R|t], so the
 // objective (1/m) sum res^T M res of one outer iteration is a quadratic form in
 // delta = vec(Theta - Theta0).  One pass over the correspondences reduces it to 74 doubles
-// per pair (f64 matrix instructions within a wave, one wave and one slab per chunk);
+// per pair (f64 matrix instructions within a wave, four waves per slab of source points);
 // the Gauss-Newton iterations on the 6 Euler parameters then cost O(1) each and run in the
 // solve kernel, which also applies the reference's convergence test and produces the next
 // float transformation with the reference's applyState arithmetic (gicp.hpp:619-634).

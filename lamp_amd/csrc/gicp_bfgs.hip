@@ -33,8 +33,10 @@ constexpr int BF_NSUM = 13;  // f, M r (3), p (M r)^T (9)
 // and M = (R C1 R^T + C2)^-1 (gicp.hpp:483-497); a point without a correspondence inside
 // corr_dist gets an all-zero record, which adds exact zeros to every sum.  The number of
 // correspondences of the chunk goes to partials[(pair, chunk)][0].
+constexpr int BFP_THREADS = 64;  // one wave per slab (the count below is a wave sum)
+
 template <bool COMPACT>
-__global__ __launch_bounds__(RED_THREADS) void bfgs_prepare_kernel(
+__global__ __launch_bounds__(BFP_THREADS) void bfgs_prepare_kernel(
     const CloudDev* __restrict__ clouds, const PairDev* __restrict__ pairs,
     const PairState* __restrict__ st, const int4* __restrict__ bmap, double corr_dist2,
     double* __restrict__ partials) {
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(RED_THREADS) void bfgs_prepare_kernel(
   const int per = (n + bm.z - 1) / bm.z;
   const int i0 = bm.y * per, i1 = min(n, i0 + per);
   int count = 0;
-  for (int i = i0 + (int)threadIdx.x; i < i1; i += RED_THREADS) {
+  for (int i = i0 + (int)threadIdx.x; i < i1; i += BFP_THREADS) {
     const nnkey_t key = P.keys[i];
     const float d2 = __uint_as_float((unsigned)(key >> 32));
     const bool valid = key != NNKEY_NONE && (double)d2 < corr_dist2;  // gicp.hpp:483
@@ -114,10 +116,10 @@ hipError_t launch_bfgs_prepare(const CloudDev* clouds, const PairDev* pairs, con
                                bool compact, hipStream_t stream) {
   if (n_blocks <= 0) return hipSuccess;
   if (compact)
-    hipLaunchKernelGGL(bfgs_prepare_kernel<true>, dim3(n_blocks), dim3(RED_THREADS), 0, stream,
+    hipLaunchKernelGGL(bfgs_prepare_kernel<true>, dim3(n_blocks), dim3(BFP_THREADS), 0, stream,
                        clouds, pairs, st, bmap, corr_dist2, partials);
   else
-    hipLaunchKernelGGL(bfgs_prepare_kernel<false>, dim3(n_blocks), dim3(RED_THREADS), 0, stream,
+    hipLaunchKernelGGL(bfgs_prepare_kernel<false>, dim3(n_blocks), dim3(BFP_THREADS), 0, stream,
                        clouds, pairs, st, bmap, corr_dist2, partials);
   return hipGetLastError();
 }

@@ -28,9 +28,12 @@ static constexpr int NN_COUNTER_SLOTS = 4096;  // the evaluated-distance counter
 // number of f64 statistics per pair and outer iteration: 10 x 6 second moments
 // sum(u_k u_l M), 4 x 3 first moments sum(u_k M r0), sum(r0^T M r0), correspondence count
 static constexpr int NSTAT = 74;
-static constexpr int RED_THREADS = 64;    // linearise/reduce: one wave per workgroup (a slab of up to
-                                          // 1024 points each): small workgroups find room beside the
-                                          // lookup kernel's waves when submits run side by side
+static constexpr int RED_THREADS = 256;   // linearise/reduce: four waves per slab of up to 1024 points,
+                                          // each taking every fourth round of 64; their sums meet in
+                                          // a fixed order.  (One wave per slab, 16 rounds in a row,
+                                          // made a lone pair's reduction 20 us of its ~59 us
+                                          // iteration; four waves: 46 us per iteration, same rate
+                                          // for full-size launches.)
 static constexpr int POST_THREADS = 256;  // post-alignment reductions
 static constexpr int RED_MAX_CHUNKS = 16;
 static constexpr int RED_CHUNK_POINTS = 1024;  // source points per slab while a cloud has at most
