@@ -1242,8 +1242,8 @@ int run_batch_impl(lgicp_ctx* ctx, BatchSlot* W, BatchPlan& bp, const lgicp_cand
     all_pairs[p] = p;
     const PairDev& pd = h_pairs[p];
     // slabs of RED_CHUNK_POINTS source points (a function of the pair alone, so that its sums do
-    // not depend on the batch it travels in), one wave each: short chains keep the stragglers'
-    // iterations short
+    // not depend on the batch it travels in), one workgroup each: short chains keep the
+    // stragglers' iterations short
     h_ints[p] = std::max(1, std::min(RED_MAX_CHUNKS, (pd.n_src + RED_CHUNK_POINTS - 1) / RED_CHUNK_POINTS));
     const int tiles = bp.clouds[bp.pairs[p].tgt_cloud].n_pad / NN_TILE;
     // the exhaustive kernel may split a query tile's target sweep over up to 64 blocks; the pruned
