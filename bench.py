@@ -483,7 +483,7 @@ def main():
     if in_flight > 1:
         # What a LAMP node gets: one blocking submit per tick on a context as lgicp_create leaves
         # it (one lane).  Measured first; the lanes for the steps in flight are set up afterwards.
-        n_ser = max(2 * n_batches, min(args.steps, 8))
+        n_ser = max(2 * n_batches, min(args.steps, 16))
         barrier()
         t_ser = time.perf_counter()
         ser_acc, _, _ = collect(ctx, n_ser, 0)
