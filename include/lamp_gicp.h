@@ -144,7 +144,9 @@ typedef struct lgicp_config {
                                  once more on its own (exercises a fallback, same result), > 0 =
                                  diagnostics only: lookup cap in mm;
                                  [5] bit 0 = host round trip after every outer iteration, bit 1 = no
-                                 limit-cycle exit from the outer loop; [6] 1 = no
+                                 limit-cycle exit from the outer loop, bit 2 = the radius sweeps of
+                                 Harris / FPFH look at every point instead of skipping the
+                                 stretches of a scan that lie out of reach (same results); [6] 1 = no
                                  seeding of a lookup with the previous match, 2 = seeding but no
                                  lookup certificates (every query searches in every pass; the
                                  results are the same bits either way); [7] parts of a

@@ -59,7 +59,8 @@ static constexpr int SP_QUEUE = 128;  // neighbours waiting per point (64 trigge
 __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ surf,
                                                    const float4* __restrict__ nrm, int n,
                                                    const unsigned char* __restrict__ need,
-                                                   float r2, float* __restrict__ spfh) {
+                                                   float r2, const float4* __restrict__ boxes,
+                                                   float* __restrict__ spfh) {
   __shared__ __attribute__((aligned(16))) float tile[3 * FP_TILE];
   __shared__ int hist[4][SP_PW][33];
   __shared__ int queue[4][SP_PW][SP_QUEUE];
@@ -121,7 +122,15 @@ __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ su
     atomicAdd(&hist[wave][q][2 * FP_BINS + b3], 1);
   };
   for (int base = 0; base < n; base += FP_TILE) {
-    __syncthreads();
+    // chunks of 64 consecutive surface points whose box lies out of reach are not looked at
+    // (harris.hip); the bins are counters, the order of arrival does not matter anyway
+    unsigned reach[SP_PW], reach_any = 0;
+#pragma unroll
+    for (int q = 0; q < SP_PW; ++q) {
+      reach[q] = live[q] ? chunks_in_reach(boxes, n, base, FP_TILE / 64, lane, p[q].x, p[q].y, p[q].z, r2) : 0u;
+      reach_any |= reach[q];
+    }
+    if (!__syncthreads_or(reach_any != 0)) continue;  // (also the barrier between two tiles)
     for (int j = tid; j < FP_TILE; j += 256) {
       float4 c = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 0);
       if (base + j < n) c = surf[base + j];
@@ -132,10 +141,12 @@ __global__ __launch_bounds__(256) void spfh_kernel(const float4* __restrict__ su
     __syncthreads();
     const int jend = min(FP_TILE, n - base);  // (the rest of the tile is padding, never within the radius)
     for (int c = 0; c < jend; c += 64) {
+      const unsigned bit = 1u << (c >> 6);
+      if (!(reach_any & bit)) continue;  // wave-uniform
       const float tx = tile[c + lane], ty = tile[FP_TILE + c + lane], tz = tile[2 * FP_TILE + c + lane];
 #pragma unroll
       for (int q = 0; q < SP_PW; ++q) {
-        if (!live[q]) continue;  // wave-uniform
+        if (!(reach[q] & bit)) continue;  // wave-uniform (never set for a point that is not live)
         // radius test on the search distance (query - point, x, y, z order)
         const float ex = p[q].x - tx, ey = p[q].y - ty, ez = p[q].z - tz;
         const bool in = (ex * ex + ey * ey) + ez * ez < r2;
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(256) void fpfh_weight_kernel(const float4* __restri
 }
 
 hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float4* keys, int n_key,
-                       float r2, unsigned char* need, float* spfh, float* out,
+                       float r2, unsigned char* need, float* spfh, float* out, const float4* boxes,
                        hipStream_t stream) {
   if (n_key <= 0) return hipSuccess;
   if (n > 0) {
@@ -225,7 +236,7 @@ hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float
     hipLaunchKernelGGL(fpfh_need_kernel, dim3(blocks, ranges), dim3(256), 0, stream, surf, n, keys, n_key,
                        per_range, r2, need);
     hipLaunchKernelGGL(spfh_kernel, dim3((n + 4 * SP_PW - 1) / (4 * SP_PW)), dim3(256), 0, stream, surf, nrm, n,
-                       need, r2, spfh);
+                       need, r2, boxes, spfh);
   }
   hipLaunchKernelGGL(fpfh_weight_kernel, dim3(n_key), dim3(256), 0, stream, surf, n, keys, r2,
                      spfh, out);

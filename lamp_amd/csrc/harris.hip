@@ -7,9 +7,12 @@
 // normals only); a point is a keypoint when its response is finite, >= threshold and no
 // neighbour within the radius has a strictly larger response.
 //
-// Mapping: two exhaustive tiled sweeps (response, then suppression) with the cloud streaming
-// through LDS; the radius test uses the search distance arithmetic of the 1-NN kernel and FLANN's
-// strict `<`.  Both sweeps give a wave four points at a time and a lane a candidate (see the
+// Mapping: two tiled sweeps (response, then suppression) with the cloud streaming through LDS in
+// its own order; the radius test uses the search distance arithmetic of the 1-NN kernel and FLANN's
+// strict `<`.  A scan arrives ring by ring, so 64 consecutive points are a short arc: the boxes of
+// those chunks (chunk_boxes_kernel) let a workgroup skip the tiles, and a wave the chunks, that lie
+// farther from its points than the radius (the float gap to a box never exceeds the float distance
+// to a point inside it, so nothing within the radius is skipped and the sums keep their order).  Both sweeps give a wave four points at a time and a lane a candidate (see the
 // kernels).  Neighbours are summed
 // in ascending index (PCL visits them by ascending distance), so responses can differ from PCL's in
 // the last float bits.
@@ -20,6 +23,41 @@
 namespace lgicp {
 
 static constexpr int HR_TILE = 512;
+
+// boxes[2 c], boxes[2 c + 1]: smallest and largest finite coordinates of points 64 c .. 64 c + 63
+// (+inf / -inf where a chunk has none)
+__global__ __launch_bounds__(256) void chunk_boxes_kernel(const float4* __restrict__ xyz, int n,
+                                                          float4* __restrict__ boxes) {
+  const int lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk * 64 >= n) return;  // wave-uniform
+  const int i = chunk * 64 + lane;
+  const float inf = __builtin_inff();
+  float x0 = inf, y0 = inf, z0 = inf, x1 = -inf, y1 = -inf, z1 = -inf;
+  if (i < n) {
+    const float4 p = xyz[i];
+    // (fminf / fmaxf drop a NaN operand; infinite coordinates stay out as well)
+    if (__builtin_isfinite(p.x)) x0 = x1 = p.x;
+    if (__builtin_isfinite(p.y)) y0 = y1 = p.y;
+    if (__builtin_isfinite(p.z)) z0 = z1 = p.z;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    x0 = __builtin_fminf(x0, __shfl_xor(x0, off)), x1 = __builtin_fmaxf(x1, __shfl_xor(x1, off));
+    y0 = __builtin_fminf(y0, __shfl_xor(y0, off)), y1 = __builtin_fmaxf(y1, __shfl_xor(y1, off));
+    z0 = __builtin_fminf(z0, __shfl_xor(z0, off)), z1 = __builtin_fmaxf(z1, __shfl_xor(z1, off));
+  }
+  if (lane == 0) {
+    boxes[2 * chunk] = make_float4(x0, y0, z0, 0.f);
+    boxes[2 * chunk + 1] = make_float4(x1, y1, z1, 0.f);
+  }
+}
+
+hipError_t launch_chunk_boxes(const float4* xyz, int n, float4* boxes, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chunk_boxes_kernel, dim3(((n + 63) / 64 + 3) / 4), dim3(256), 0, stream, xyz, n, boxes);
+  return hipGetLastError();
+}
 
 // One lane per candidate, not per point: a wave owns HR_PW points at a time, its 64 lanes test 64
 // candidates of the tile in LDS against each of them, and the few that lie within the radius (a
@@ -32,6 +70,7 @@ static constexpr int HR_PW = 4;
 __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __restrict__ xyz,
                                                               const float4* __restrict__ nrm,
                                                               int n, float r2,
+                                                              const float4* __restrict__ boxes,
                                                               float* __restrict__ response) {
   __shared__ __attribute__((aligned(16))) float tile[6 * HR_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,7 +89,14 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
     count[q] = 0;
   }
   for (int base = 0; base < n; base += HR_TILE) {
-    __syncthreads();
+    unsigned reach[HR_PW], reach_any = 0;
+#pragma unroll
+    for (int q = 0; q < HR_PW; ++q) {
+      reach[q] = chunks_in_reach(boxes, n, base, HR_TILE / 64, lane, px[q], py[q], pz[q], r2);
+      reach_any |= reach[q];
+    }
+    // (also the barrier that keeps the previous tile in place until every wave is done with it)
+    if (!__syncthreads_or(reach_any != 0)) continue;
     for (int j = tid; j < HR_TILE; j += 256) {
       float4 q = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 0), m = make_float4(0, 0, 0, 0);
       if (base + j < n) {
@@ -67,9 +113,12 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
     __syncthreads();
     const int jend = min(HR_TILE, n - base);  // (the rest of the tile is padding, never within the radius)
     for (int c = 0; c < jend; c += 64) {
+      const unsigned bit = 1u << (c >> 6);
+      if (!(reach_any & bit)) continue;  // wave-uniform
       const float tx = tile[c + lane], ty = tile[HR_TILE + c + lane], tz = tile[2 * HR_TILE + c + lane];
 #pragma unroll
       for (int q = 0; q < HR_PW; ++q) {
+        if (!(reach[q] & bit)) continue;  // wave-uniform
         const float dx = px[q] - tx, dy = py[q] - ty, dz = pz[q] - tz;
         const float d2 = (dx * dx + dy * dy) + dz * dz;
         unsigned long long m = __ballot(d2 < r2);
@@ -116,6 +165,7 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
 __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restrict__ xyz,
                                                          const float* __restrict__ response,
                                                          int n, float r2, float threshold,
+                                                         const float4* __restrict__ boxes,
                                                          unsigned char* __restrict__ is_key) {
   __shared__ __attribute__((aligned(16))) float tile[4 * HR_TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,7 +185,13 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restric
   }
   const bool block_any = __syncthreads_count(any) != 0;
   for (int base = 0; block_any && base < n; base += HR_TILE) {
-    __syncthreads();
+    unsigned reach[HR_PW], reach_any = 0;
+#pragma unroll
+    for (int q = 0; q < HR_PW; ++q) {
+      reach[q] = cand[q] ? chunks_in_reach(boxes, n, base, HR_TILE / 64, lane, px[q], py[q], pz[q], r2) : 0u;
+      reach_any |= reach[q];
+    }
+    if (!__syncthreads_or(reach_any != 0)) continue;  // (also the barrier between two tiles)
     for (int j = tid; j < HR_TILE; j += 256) {
       float4 q = make_float4(PAD_COORD, PAD_COORD, PAD_COORD, 0);
       float rj = -1.f;
@@ -152,11 +208,13 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restric
     if (!(cand[0] || cand[1] || cand[2] || cand[3])) continue;  // wave-uniform
     const int jend = min(HR_TILE, n - base);  // (the rest of the tile is padding, never within the radius)
     for (int c = 0; c < jend; c += 64) {
+      const unsigned bit = 1u << (c >> 6);
+      if (!(reach_any & bit)) continue;  // wave-uniform
       const float tx = tile[c + lane], ty = tile[HR_TILE + c + lane], tz = tile[2 * HR_TILE + c + lane];
       const float rj = tile[3 * HR_TILE + c + lane];
 #pragma unroll
       for (int q = 0; q < HR_PW; ++q) {
-        if (!cand[q]) continue;  // wave-uniform
+        if (!cand[q] || !(reach[q] & bit)) continue;  // wave-uniform
         const float dx = px[q] - tx, dy = py[q] - ty, dz = pz[q] - tz;
         const float d2 = (dx * dx + dy * dy) + dz * dz;
         if (__ballot(d2 < r2 && ri[q] < rj)) cand[q] = false;
@@ -169,13 +227,14 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float4* __restric
 }
 
 hipError_t launch_harris(const float4* xyz, const float4* nrm, int n, float r2, float threshold,
-                         float* response, unsigned char* is_key, hipStream_t stream) {
+                         float* response, unsigned char* is_key, const float4* boxes,
+                         hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   const dim3 block(256);
   hipLaunchKernelGGL(harris_response_kernel, dim3((n + 4 * HR_PW - 1) / (4 * HR_PW)), block, 0, stream, xyz, nrm, n, r2,
-                     response);
+                     boxes, response);
   hipLaunchKernelGGL(harris_nms_kernel, dim3((n + 4 * HR_PW - 1) / (4 * HR_PW)), block, 0, stream, xyz, response, n, r2,
-                     threshold, is_key);
+                     threshold, boxes, is_key);
   return hipGetLastError();
 }
 

@@ -249,11 +249,40 @@ hipError_t launch_normals_radius(const float4* xyz, int n, float r2, float4* nor
 
 // FPFH at n_key keypoints over a surface of n points (radius^2 = r2); need[n], spfh[n*33]
 // are scratch, out is [n_key][33]
+// boxes: the surface's chunk boxes (launch_chunk_boxes) or null
 hipError_t launch_fpfh(const float4* surf, const float4* nrm, int n, const float4* keys, int n_key,
-                       float r2, unsigned char* need, float* spfh, float* out, hipStream_t stream);
+                       float r2, unsigned char* need, float* spfh, float* out, const float4* boxes,
+                       hipStream_t stream);
 
-// Harris3D response + non-maxima suppression (radius^2 = r2); response[n], is_key[n]
+// boxes[2 c], boxes[2 c + 1]: smallest and largest finite coordinates of points 64 c .. 64 c + 63 of a
+// cloud in its own order (2 * ceil(n / 64) entries): what the radius sweeps of the feature front end
+// use to skip the stretches of a scan that lie out of reach
+hipError_t launch_chunk_boxes(const float4* xyz, int n, float4* boxes, hipStream_t stream);
+
+#ifdef __HIPCC__
+// Chunks of the tile that starts at `base` (bit k: points base + 64 k ..) whose box lies within the
+// radius of (px, py, pz); lanes 0 .. tile / 64 - 1 test one chunk each.  Without boxes: every chunk.
+__device__ __forceinline__ unsigned chunks_in_reach(const float4* __restrict__ boxes, int n, int base,
+                                                    int tile_chunks, int lane, float px, float py,
+                                                    float pz, float r2) {
+  if (!boxes) return 0xFFFFFFFFu;
+  const int ch = (base >> 6) + lane;
+  bool in = false;
+  if (lane < tile_chunks && ch * 64 < n) {
+    const float4 b0 = boxes[2 * ch], b1 = boxes[2 * ch + 1];
+    const float gx = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.x - px, px - b1.x));
+    const float gy = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.y - py, py - b1.y));
+    const float gz = __builtin_fmaxf(0.f, __builtin_fmaxf(b0.z - pz, pz - b1.z));
+    in = (gx * gx + gy * gy) + gz * gz < r2;
+  }
+  return (unsigned)__ballot(in);
+}
+#endif
+
+// Harris3D response + non-maxima suppression (radius^2 = r2); response[n], is_key[n]; boxes: the
+// cloud's chunk boxes (launch_chunk_boxes) or null (every chunk is swept; same result)
 hipError_t launch_harris(const float4* xyz, const float4* nrm, int n, float r2, float threshold,
-                         float* response, unsigned char* is_key, hipStream_t stream);
+                         float* response, unsigned char* is_key, const float4* boxes,
+                         hipStream_t stream);
 
 }  // namespace lgicp

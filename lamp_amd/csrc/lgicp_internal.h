@@ -425,8 +425,10 @@ struct TeaserJob {
 struct FeatureScratch {
   DevBuf<float> resp, spfh;
   DevBuf<unsigned char> key, need;
-  DevBuf<float4> kp;
-  void release() { resp.release(), spfh.release(), key.release(), need.release(), kp.release(); }
+  DevBuf<float4> kp, boxes;
+  void release() {
+    resp.release(), spfh.release(), key.release(), need.release(), kp.release(), boxes.release();
+  }
 };
 constexpr int FEATURE_LANES = 4;
 // buffers of the descriptor matcher, reused from pair to pair (work of successive pairs is

@@ -246,10 +246,12 @@ int lgicp_fpfh(lgicp_ctx* ctx, const float* surface_xyz, const float* surface_no
   unsigned char* d_need = d.alloc<unsigned char>(n);
   float* d_spfh = d.alloc<float>(n * 33);
   float* d_out = d.alloc<float>(n_key * 33);
-  if (!d_s || !d_n || !d_k || !d_need || !d_spfh || !d_out)
+  float4* d_boxes = d.alloc<float4>(2 * ((n + 63) / 64) + 2);
+  if (!d_s || !d_n || !d_k || !d_need || !d_spfh || !d_out || !d_boxes)
     return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
+  HIP_TRY(ctx, launch_chunk_boxes(d_s, (int)n, d_boxes, ctx->stream));
   HIP_TRY(ctx, launch_fpfh(d_s, d_n, (int)n, d_k, (int)n_key, (float)(radius * radius), d_need,
-                           d_spfh, d_out, ctx->stream));
+                           d_spfh, d_out, d_boxes, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * n_key * 33, hipMemcpyDeviceToHost,
                               ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -426,12 +428,17 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   if (lane < 0 || lane >= lgicp_ctx::FEATURE_SETS * FEATURE_LANES || lane >= ctx->n_slots) lane = 0;
   hipStream_t st = ctx->slot[lane].stream;
   FeatureScratch& d = ctx->feature_scratch.get()[lane];
-  if (d.resp.reserve((size_t)n) != hipSuccess || d.key.reserve((size_t)n) != hipSuccess)
+  if (d.resp.reserve((size_t)n) != hipSuccess || d.key.reserve((size_t)n) != hipSuccess ||
+      d.boxes.reserve(2 * (((size_t)n + 63) / 64)) != hipSuccess)
     return fail(ctx, LGICP_E_NOMEM, "device allocation failed");
   float* d_resp = d.resp.p;
   unsigned char* d_key = d.key.p;
+  // boxes of the cloud's 64-point chunks: both radius sweeps below skip what lies out of reach
+  // (reserved[5] bit 2: sweep everything, for cross-checks -- the results are the same bits)
+  const float4* d_boxes = (cfg.reserved[5] & 4) ? nullptr : d.boxes.p;
+  if (d_boxes) HIP_TRY(ctx, launch_chunk_boxes(d_xyz, n, d.boxes.p, st));
   const float hr2 = (float)(cfg.harris_radius * cfg.harris_radius);
-  HIP_TRY(ctx, launch_harris(d_xyz, d_nrm, n, hr2, (float)cfg.harris_threshold, d_resp, d_key, st));
+  HIP_TRY(ctx, launch_harris(d_xyz, d_nrm, n, hr2, (float)cfg.harris_threshold, d_resp, d_key, d_boxes, st));
   std::vector<unsigned char> flags((size_t)n);
   std::vector<float4> pts((size_t)n);
   HIP_TRY(ctx, hipMemcpyAsync(flags.data(), d_key, (size_t)n, hipMemcpyDeviceToHost, st));
@@ -462,7 +469,7 @@ int compute_cloud_features(lgicp_ctx* ctx, const float4* d_xyz, const float4* d_
   HIP_TRY(ctx, hipMemcpyAsync(d_out + 33 * k, out->xyz.data(), sizeof(float) * 3 * k, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(d_kp, kp.data(), sizeof(float4) * k, hipMemcpyHostToDevice, st));
   const float fr2 = (float)(cfg.sac_features_radius * cfg.sac_features_radius);
-  HIP_TRY(ctx, launch_fpfh(d_xyz, d_nrm, n, d_kp, (int)k, fr2, d_need, d_spfh, d_out, st));
+  HIP_TRY(ctx, launch_fpfh(d_xyz, d_nrm, n, d_kp, (int)k, fr2, d_need, d_spfh, d_out, d_boxes, st));
   out->feat.resize(33 * k);
   HIP_TRY(ctx, hipMemcpyAsync(out->feat.data(), d_out, sizeof(float) * 33 * k, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -214,3 +214,32 @@ def test_c4_submits_side_by_side_equal_submits_in_turn(method):
         for a, b in zip(a_list, b_list):
             assert a["status"] == b["status"] and a["init_fitness"] == b["init_fitness"]
             assert np.array_equal(a["T_init"], b["T_init"]) and np.array_equal(a["T_icp"], b["T_icp"])
+
+
+@pytest.mark.parametrize("method", ["features", "teaser"])
+def test_feature_sweeps_skip_only_what_is_out_of_reach(method):
+    """The radius sweeps of Harris3D and FPFH skip the 64-point stretches of a scan whose box lies
+    farther away than the radius.  With that switched off (reserved[5] bit 2: every point is looked
+    at) a submit returns the same bits: keypoints, descriptors, initial alignment, refined pose."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    work = Workload("C4", pairs=8, points=8192, keyframes=8)
+    init = capi.INIT_FEATURES if method == "features" else capi.INIT_TEASERPP
+    outs = []
+    for bits in (0, 4):
+        res = [0] * 8
+        res[5] = bits
+        c = capi.Context(init_method=init, harris_radius=RADIUS, transform_thresholding=0,
+                         reserved=(capi.C.c_int * 8)(*res))
+        try:
+            work.register(c)
+            outs.append([capi.result_to_dict(r) for r in c.submit(work.candidates())])
+        finally:
+            c.close()
+    assert sum(r["init_fitness"] > 0 for r in outs[0]) >= 4      # the initialisation did run
+    for a, b in zip(*outs):
+        assert a["status"] == b["status"] and a["iterations"] == b["iterations"]
+        assert a["init_fitness"] == b["init_fitness"]
+        assert np.array_equal(a["T_init"], b["T_init"]) and np.array_equal(a["T_icp"], b["T_icp"])
+        assert a["fitness"] == b["fitness"]
+

@@ -8,7 +8,10 @@ from lamp_amd.workload import Workload
 
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 n_kf = n_pairs // 4
-c = capi.Context(init_method=capi.INIT_TEASERPP, harris_radius=0.5, transform_thresholding=0)
+res = [0] * 8
+res[5] = int(os.environ.get("PROBE_R5", "0"))   # 4: radius sweeps of the front end without chunk boxes
+c = capi.Context(init_method=capi.INIT_TEASERPP, harris_radius=0.5, transform_thresholding=0,
+                 reserved=(capi.C.c_int * 8)(*res))
 works = [Workload("C4", pairs=n_pairs, keyframes=n_kf, shard=s, key_offset=100000 * s) for s in range(3)]
 for i, w in enumerate(works + works[:1]):
     t0 = time.perf_counter()
