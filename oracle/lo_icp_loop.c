@@ -268,12 +268,17 @@ int lo_perform_alignment(const lo_icp_params* p, const float* src_xyz, const flo
   const double fitness =
       lo_fitness_score(src_xyz, n_src, tgt_xyz, n_tgt, T, corr32, gp.use_kdtree, gp.threads);
   if (p->covariance_method == LO_COV_POINT2PLANE) {
-    for (int i = 0; i < 16; ++i)
-      if (!isfinite(T[i])) { /* a non-finite T makes every icp_result point non-finite */
-        free(corr32);
-        out->status = LO_FAIL_NONFINITE;
-        return out->status;
-      }
+    /* "Catch nan of infs in icp result" (:556-558): icp_result is T applied to the source, so a
+     * non-finite T spoils every point and a non-finite source point stays what it is */
+    int bad = 0;
+    for (int i = 0; i < 16; ++i) bad |= !isfinite(T[i]);
+    for (int i = 0; i < n_src && !bad; ++i)
+      bad = !isfinite(src_xyz[3 * i]) || !isfinite(src_xyz[3 * i + 1]) || !isfinite(src_xyz[3 * i + 2]);
+    if (bad) {
+      free(corr32);
+      out->status = LO_FAIL_NONFINITE;
+      return out->status;
+    }
   }
   lo_pose delta;
   for (int a = 0; a < 3; ++a) {

@@ -867,6 +867,54 @@ def test_lookup_certificates_change_nothing():
             assert np.array_equal(np.asarray(a["covariance"]), np.asarray(b["covariance"]), equal_nan=True)
 
 
+def test_bfgs_back_end_on_degenerate_pairs():
+    """The pairs the reference's optimiser cannot work with, under LGICP_SOLVER_BFGS: a source ten
+    metres away from its target (fewer than four correspondences: NotEnoughPointsException,
+    gicp.hpp:225-233 -> the loop ends unconverged), a source of five points (below
+    k_correspondences, gicp.hpp:72-79), a source with non-finite points, exact duplicates in the
+    target.  Status and convergence flag equal those of the oracle's BFGS (iteration count and pose
+    too where the pair is accepted), and the submit returns (no pair keeps the batch in the loop)."""
+    from lamp_amd import capi
+    rng = np.random.default_rng(5)
+    src, sn, tgt, tn, _ = F.make_pair(5000, 77, rot_deg=2.0, trans=0.15)
+    far = src + np.float32([10.0, 0.0, 0.0])
+    tiny, tiny_n = src[:5].copy(), sn[:5].copy()
+    holes = src.copy()
+    holes[::97] = np.nan
+    dup = tgt.copy()
+    dup[100:200] = dup[300:400]
+    cases = [("plain", src, sn, tgt, tn), ("far", far, sn, tgt, tn), ("tiny", tiny, tiny_n, tgt, tn),
+             ("holes", holes, sn, tgt, tn), ("duplicates", src, sn, dup, tn)]
+    c = capi.Context(init_method=capi.INIT_IDENTITY, solver=capi.SOLVER_BFGS, transform_thresholding=0)
+    try:
+        pairs = []
+        for i, (_, s_xyz, s_n, t_xyz, t_n) in enumerate(cases):
+            # (keys ten apart: the base-station block would accumulate key +- 2 into a cloud)
+            _register(c, 1000 + 10 * i, t_xyz, t_n)
+            _register(c, 2000 + 10 * i, s_xyz, s_n)
+            pairs.append((2000 + 10 * i, 1000 + 10 * i))
+        res = [capi.result_to_dict(r) for r in c.submit(pairs)]
+    finally:
+        c.close()
+    ident = O.pose_from_quat([1, 0, 0, 0], [0, 0, 0])
+    for (name, s_xyz, s_n, t_xyz, t_n), d in zip(cases, res):
+        ref = O.perform_alignment(O.base_icp_params(init_method=O.INIT_IDENTITY, solver=O.SOLVER_BFGS,
+                                                    sum_order=1, transform_thresholding=0),
+                                  s_xyz, s_n, t_xyz, t_n, s_xyz, t_n, ident)
+        # (the oracle numbers its outcomes on its own: lo_status in oracle/lamp_oracle.h)
+        want = {0: capi.PAIR_OK, 1: capi.PAIR_EMPTY_CLOUD, 2: capi.PAIR_NONFINITE, 3: capi.PAIR_NOT_CONVERGED,
+                4: capi.PAIR_FITNESS, 5: capi.PAIR_TRANSFORM}[ref["status"]]
+        assert d["status"] == want, (name, d["status"], ref["status"])
+        assert d["converged"] == bool(ref["converged"]), name
+        if d["status"] == 0:
+            # (a pair that ends rejected wanders through garbage alignments, where the line search
+            # turns the last bit of a sum into another path; only the outcome is compared there)
+            assert d["iterations"] == ref["iterations"], (name, d["iterations"], ref["iterations"])
+            ang, te = O.pose_gap(ref["T_icp"], d["T_icp"])
+            assert ang < 1e-4 and te < 1e-4, (name, ang, te)
+    assert res[0]["status"] == 0 and res[1]["status"] != 0
+
+
 # ------------------------------------------------------------------ normals, observability
 def test_compute_normals_matches_oracle(ctx):
     """lamp_utils::ComputeNormals (PointCloudUtils.h:38-62).  Pinned by the reference on the
