@@ -867,13 +867,15 @@ def test_lookup_certificates_change_nothing():
             assert np.array_equal(np.asarray(a["covariance"]), np.asarray(b["covariance"]), equal_nan=True)
 
 
-def test_bfgs_back_end_on_degenerate_pairs():
-    """The pairs the reference's optimiser cannot work with, under LGICP_SOLVER_BFGS: a source ten
+@pytest.mark.parametrize("solver", ["bfgs", "gn"])
+def test_degenerate_pairs_end_as_the_oracle_says(solver):
+    """The pairs the reference's optimiser cannot work with, under either inner solver: a source ten
     metres away from its target (fewer than four correspondences: NotEnoughPointsException,
     gicp.hpp:225-233 -> the loop ends unconverged), a source of five points (below
     k_correspondences, gicp.hpp:72-79), a source with non-finite points, exact duplicates in the
-    target.  Status and convergence flag equal those of the oracle's BFGS (iteration count and pose
-    too where the pair is accepted), and the submit returns (no pair keeps the batch in the loop)."""
+    target.  Status and convergence flag equal those of the oracle's run with the same solver
+    (iteration count and pose too where the pair is accepted), and the submit returns (no pair keeps
+    the batch in the loop)."""
     from lamp_amd import capi
     rng = np.random.default_rng(5)
     src, sn, tgt, tn, _ = F.make_pair(5000, 77, rot_deg=2.0, trans=0.15)
@@ -885,7 +887,9 @@ def test_bfgs_back_end_on_degenerate_pairs():
     dup[100:200] = dup[300:400]
     cases = [("plain", src, sn, tgt, tn), ("far", far, sn, tgt, tn), ("tiny", tiny, tiny_n, tgt, tn),
              ("holes", holes, sn, tgt, tn), ("duplicates", src, sn, dup, tn)]
-    c = capi.Context(init_method=capi.INIT_IDENTITY, solver=capi.SOLVER_BFGS, transform_thresholding=0)
+    bfgs = solver == "bfgs"
+    c = capi.Context(init_method=capi.INIT_IDENTITY, transform_thresholding=0,
+                     solver=capi.SOLVER_BFGS if bfgs else capi.SOLVER_GAUSS_NEWTON)
     try:
         pairs = []
         for i, (_, s_xyz, s_n, t_xyz, t_n) in enumerate(cases):
@@ -898,8 +902,9 @@ def test_bfgs_back_end_on_degenerate_pairs():
         c.close()
     ident = O.pose_from_quat([1, 0, 0, 0], [0, 0, 0])
     for (name, s_xyz, s_n, t_xyz, t_n), d in zip(cases, res):
-        ref = O.perform_alignment(O.base_icp_params(init_method=O.INIT_IDENTITY, solver=O.SOLVER_BFGS,
-                                                    sum_order=1, transform_thresholding=0),
+        ref = O.perform_alignment(O.base_icp_params(init_method=O.INIT_IDENTITY, transform_thresholding=0,
+                                                    solver=O.SOLVER_BFGS if bfgs else O.SOLVER_GN,
+                                                    sum_order=1 if bfgs else 0),
                                   s_xyz, s_n, t_xyz, t_n, s_xyz, t_n, ident)
         # (the oracle numbers its outcomes on its own: lo_status in oracle/lamp_oracle.h)
         want = {0: capi.PAIR_OK, 1: capi.PAIR_EMPTY_CLOUD, 2: capi.PAIR_NONFINITE, 3: capi.PAIR_NOT_CONVERGED,
