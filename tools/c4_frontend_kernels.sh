@@ -1,3 +1,6 @@
+# Kernel times of the feature front end (Harris, FPFH) of cold TEASERPP batches with the chunk boxes
+# (default) and without (lgicp_config.reserved[5] bit 2): rocprofv3 --kernel-trace --stats around
+# tools/c4_cold_probe.py, once per setting.  usage (GPU box, repository root): bash tools/c4_frontend_kernels.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for R in 0 4; do
   rm -rf gpurun_out/c4k_$R
