@@ -64,9 +64,15 @@ hipError_t launch_chunk_boxes(const float4* xyz, int n, float4* boxes, hipStream
 // ballot) are added to the point's sums one after the other in ascending index - the order the
 // sums had with one lane per point, so the responses are the same floats, but a 16k-point cloud is
 // 1,024 workgroups instead of 64.  The seven sums of a point sit in seven lanes (lane 0: n_x n_x,
-// 1: n_y n_x, 2: n_z n_x, 3: n_x n_y, 4: n_y n_y, 5: n_z n_y, 6: n_z n_z), each lane reading its two
-// factors of a neighbour's normal from LDS: a neighbour costs one multiplication and one addition.
+// 1: n_y n_x, 2: n_z n_x, 3: n_x n_y, 4: n_y n_y, 5: n_z n_y, 6: n_z n_z): a neighbour costs one
+// multiplication and one addition.  Its normal is not fetched from LDS when its turn comes (two
+// dependent round trips per neighbour were most of the kernel's time): every lane holds the normal
+// of its own candidate, read once per chunk that has a neighbour at all, and a neighbour's three
+// components are broadcast out of its lane, each sum's lane picking its two factors.
 static constexpr int HR_PW = 4;
+__device__ __forceinline__ float bcast(float v, int l) {  // lane l's value, l wave-uniform
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
 __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __restrict__ xyz,
                                                               const float4* __restrict__ nrm,
                                                               int n, float r2,
@@ -78,8 +84,9 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
   float px[HR_PW], py[HR_PW], pz[HR_PW];
   float sum[HR_PW];  // lane L < 7: sum L of the point
   unsigned count[HR_PW];
-  // the planes of the tile (3: n_x, 4: n_y, 5: n_z) this lane's factors come from
-  const int plane_a = 3 + (lane < 6 ? lane % 3 : 2), plane_b = 3 + (lane < 3 ? 0 : lane < 6 ? 1 : 2);
+  // the components of a neighbour's normal (0: n_x, 1: n_y, 2: n_z) this lane's factors are
+  const int comp_a = lane < 6 ? lane % 3 : 2, comp_b = lane < 3 ? 0 : lane < 6 ? 1 : 2;
+  const bool a_x = comp_a == 0, a_y = comp_a == 1, b_x = comp_b == 0, b_y = comp_b == 1;
 #pragma unroll
   for (int q = 0; q < HR_PW; ++q) {
     float4 p = make_float4(__builtin_nanf(""), 0, 0, 0);
@@ -116,18 +123,24 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
       const unsigned bit = 1u << (c >> 6);
       if (!(reach_any & bit)) continue;  // wave-uniform
       const float tx = tile[c + lane], ty = tile[HR_TILE + c + lane], tz = tile[2 * HR_TILE + c + lane];
+      float cnx = 0.f, cny = 0.f, cnz = 0.f;  // this lane's candidate's normal
+      bool have_normals = false;              // wave-uniform
 #pragma unroll
       for (int q = 0; q < HR_PW; ++q) {
         if (!(reach[q] & bit)) continue;  // wave-uniform
         const float dx = px[q] - tx, dy = py[q] - ty, dz = pz[q] - tz;
         const float d2 = (dx * dx + dy * dy) + dz * dz;
         unsigned long long m = __ballot(d2 < r2);
+        if (m && !have_normals) {
+          cnx = tile[3 * HR_TILE + c + lane], cny = tile[4 * HR_TILE + c + lane], cnz = tile[5 * HR_TILE + c + lane];
+          have_normals = true;
+        }
         while (m) {  // wave-uniform: the neighbours among these 64, ascending
-          const int j = c + __builtin_ctzll(m);
+          const int l = __builtin_ctzll(m);
           m &= m - 1;
-          const float fa = tile[plane_a * HR_TILE + j], fb = tile[plane_b * HR_TILE + j];
-          // lane 0's first factor is n_x
-          if (!isfinite(__uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fa))))) continue;
+          const float sx = bcast(cnx, l), sy = bcast(cny, l), sz = bcast(cnz, l);
+          if (!isfinite(sx)) continue;  // a neighbour without a normal does not count
+          const float fa = a_x ? sx : (a_y ? sy : sz), fb = b_x ? sx : (b_y ? sy : sz);
           sum[q] += fa * fb;
           ++count[q];
         }
