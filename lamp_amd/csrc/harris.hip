@@ -123,26 +123,37 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float4* __re
       const unsigned bit = 1u << (c >> 6);
       if (!(reach_any & bit)) continue;  // wave-uniform
       const float tx = tile[c + lane], ty = tile[HR_TILE + c + lane], tz = tile[2 * HR_TILE + c + lane];
-      float cnx = 0.f, cny = 0.f, cnz = 0.f;  // this lane's candidate's normal
-      bool have_normals = false;              // wave-uniform
+      // The wave's points follow each other in the scan and share most of their neighbours: the
+      // candidates within the radius of any of them are gone through once, in ascending order, a
+      // candidate's products are formed once and added to the sums of the points it is a neighbour
+      // of - every point still receives its neighbours in ascending index.
+      unsigned long long mq[HR_PW], any = 0;
 #pragma unroll
       for (int q = 0; q < HR_PW; ++q) {
+        mq[q] = 0;
         if (!(reach[q] & bit)) continue;  // wave-uniform
         const float dx = px[q] - tx, dy = py[q] - ty, dz = pz[q] - tz;
         const float d2 = (dx * dx + dy * dy) + dz * dz;
-        unsigned long long m = __ballot(d2 < r2);
-        if (m && !have_normals) {
-          cnx = tile[3 * HR_TILE + c + lane], cny = tile[4 * HR_TILE + c + lane], cnz = tile[5 * HR_TILE + c + lane];
-          have_normals = true;
-        }
-        while (m) {  // wave-uniform: the neighbours among these 64, ascending
-          const int l = __builtin_ctzll(m);
-          m &= m - 1;
-          const float sx = bcast(cnx, l), sy = bcast(cny, l), sz = bcast(cnz, l);
-          if (!isfinite(sx)) continue;  // a neighbour without a normal does not count
-          const float fa = a_x ? sx : (a_y ? sy : sz), fb = b_x ? sx : (b_y ? sy : sz);
-          sum[q] += fa * fb;
-          ++count[q];
+        mq[q] = __ballot(d2 < r2);
+        any |= mq[q];
+      }
+      if (!any) continue;
+      // this lane's candidate's normal
+      const float cnx = tile[3 * HR_TILE + c + lane], cny = tile[4 * HR_TILE + c + lane], cnz = tile[5 * HR_TILE + c + lane];
+      while (any) {  // wave-uniform
+        const int l = __builtin_ctzll(any);
+        any &= any - 1;
+        const float sx = bcast(cnx, l), sy = bcast(cny, l), sz = bcast(cnz, l);
+        const bool counts = isfinite(sx);  // a neighbour without a normal does not count
+        const float fa = a_x ? sx : (a_y ? sy : sz), fb = b_x ? sx : (b_y ? sy : sz);
+        const float prod = fa * fb;
+        // No branch per point: a point the candidate is no neighbour of adds +0, which leaves a
+        // sum as it is (the sums start at +0 and a sum of floats that started at +0 is never -0).
+#pragma unroll
+        for (int q = 0; q < HR_PW; ++q) {
+          const bool take = counts && ((mq[q] >> l) & 1ull);  // wave-uniform
+          sum[q] += take ? prod : 0.f;
+          count[q] += take ? 1u : 0u;
         }
       }
     }
