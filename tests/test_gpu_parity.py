@@ -346,6 +346,26 @@ def test_align_with_an_explicit_guess_and_the_reference_solver():
         c.close()
 
 
+@pytest.mark.parametrize("n,seed,rot_deg,trans", [(2500, 5, 2.0, 0.15), (6000, 6, 3.0, 0.3)])
+def test_device_lands_where_an_independent_minimiser_lands(n, seed, rot_deg, trans):
+    """The default back end against an implementation that shares nothing with the oracle's solvers
+    (numpy objective in double precision + MINPACK's Levenberg-Marquardt,
+    tests/test_independent_minimiser.py): the same float matrix up to its last bit."""
+    from lamp_amd import capi
+    from tests.test_independent_minimiser import _gicp_numpy
+    src, sn, tgt, tn, _ = F.make_pair(n, seed, rot_deg=rot_deg, trans=trans)
+    T_np = _gicp_numpy(src, sn, tgt, tn)
+    c = capi.Context(init_method=capi.INIT_IDENTITY)
+    try:
+        got = c.align(src, sn, tgt, tn, np.eye(4, dtype=np.float32))
+    finally:
+        c.close()
+    assert got["converged"]
+    ang, te = O.pose_gap(T_np, got["T"])
+    assert ang < 1e-8 and te < 1e-8, (ang, te)
+    assert np.max(np.abs(T_np.astype(np.float64) - np.asarray(got["T"], np.float64))) < 2e-7
+
+
 def test_reference_known_answer_with_the_reference_solver():
     """TestLoopComputation.PerformAlignment (loop_closure/test/test_loop_computation.cc:125-182):
     corner against the corner shifted by (1, -0.001, 0), the test's perturbed odometry poses, the base
