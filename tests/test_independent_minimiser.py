@@ -62,3 +62,27 @@ def test_gauss_newton_lands_where_an_independent_minimiser_lands(n, seed, rot_de
     ang_b, te_b = O.pose_gap(T_np, bf["T"])
     assert ang_b < 1e-4 and te_b < 2e-4, (ang_b, te_b)
     assert te <= te_b and ang <= ang_b
+
+
+def test_knn_covariances_against_lapack():
+    """computeCovariances' k-NN branch (gicp.hpp:83-155) with LAPACK's SVD (numpy) in place of the
+    oracle's own Jacobi iteration: 20 nearest neighbours, raw second moments minus the mean's outer
+    product, singular values replaced by (1, 1, 1e-3).  A point whose two largest singular values
+    nearly coincide has no unique U; the rebuilt matrix does not depend on that (it is
+    1 - (1 - 1e-3) u3 u3^T), only a nearly vanishing gap between the two smallest does."""
+    xyz, _ = F.random_room_scan(3000, 21)
+    got = O.cov_knn(xyz, 20, 1e-3, threads=4)
+    idx, _ = O.knn_brute(xyz, xyz, 20)
+    P32 = xyz[idx]                                           # n x 20 x 3
+    mean = P32.astype(np.float64).mean(axis=1)
+    # (the reference multiplies two floats before it widens: `cov(0, 0) += pt.x * pt.x`)
+    prod = (P32[:, :, :, None] * P32[:, :, None, :]).astype(np.float64)
+    raw = prod.sum(axis=1) / 20.0 - np.einsum("ni,nj->nij", mean, mean)
+    U, sv, _ = np.linalg.svd(raw)
+    want = np.einsum("nik,k,njk->nij", U, np.array([1.0, 1.0, 1e-3]), U)
+    err = np.abs(got - want).max(axis=(1, 2))
+    gap = (sv[:, 1] - sv[:, 2]) / sv[:, 0]                   # what u3 is conditioned by
+    well = gap > 1e-6
+    assert well.mean() > 0.99
+    assert err[well].max() < 1e-12, err[well].max()          # measured: 8e-15
+    assert np.median(err) < 1e-14
