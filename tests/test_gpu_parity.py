@@ -350,9 +350,9 @@ def test_align_with_an_explicit_guess_and_the_reference_solver():
 def test_device_lands_where_an_independent_minimiser_lands(n, seed, rot_deg, trans):
     """The default back end against an implementation that shares nothing with the oracle's solvers
     (numpy objective in double precision + MINPACK's Levenberg-Marquardt,
-    tests/test_independent_minimiser.py): the same float matrix up to its last bit."""
+    tests/test_independent_anchors.py): the same float matrix up to its last bit."""
     from lamp_amd import capi
-    from tests.test_independent_minimiser import _gicp_numpy
+    from tests.test_independent_anchors import _gicp_numpy
     src, sn, tgt, tn, _ = F.make_pair(n, seed, rot_deg=rot_deg, trans=trans)
     T_np = _gicp_numpy(src, sn, tgt, tn)
     c = capi.Context(init_method=capi.INIT_IDENTITY)

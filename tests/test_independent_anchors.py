@@ -86,3 +86,65 @@ def test_knn_covariances_against_lapack():
     assert well.mean() > 0.99
     assert err[well].max() < 1e-12, err[well].max()          # measured: 8e-15
     assert np.median(err) < 1e-14
+
+
+def test_nearest_neighbours_against_scipy_kdtree():
+    """The oracle's kd-tree and its exhaustive search against scipy's cKDTree (double precision):
+    same neighbours wherever the float distances leave no tie (FLANN's L2_Simple arithmetic differs
+    from the double distance in the last float bit at most)."""
+    spatial = pytest.importorskip("scipy.spatial")
+    rng = np.random.default_rng(3)
+    tgt, _ = F.random_room_scan(4000, 31)
+    q = tgt[rng.choice(len(tgt), 1500, replace=False)] + rng.normal(0, 0.05, (1500, 3)).astype(np.float32)
+    tree = spatial.cKDTree(tgt.astype(np.float64))
+    d_ref, i_ref = tree.query(q.astype(np.float64), k=21)
+    for k in (1, 20):
+        i_kd, d_kd = O.kdtree_knn(q, tgt, k, threads=4)
+        i_bf, d_bf = (O.nn_brute(q, tgt) if k == 1 else O.knn_brute(q, tgt, k))
+        i_bf, d_bf = np.reshape(i_bf, (len(q), k)), np.reshape(d_bf, (len(q), k))
+        assert np.array_equal(d_kd, d_bf)                      # the two oracles: the same floats
+        # no tie between a neighbour and the next one (relative gap of the squared distances)
+        gaps = np.diff(d_ref[:, :k + 1] ** 2, axis=1) / np.maximum(d_ref[:, 1:k + 1] ** 2, 1e-12)
+        clear = gaps.min(axis=1) > 1e-5
+        assert clear.mean() > 0.95
+        assert np.array_equal(i_kd[clear], i_ref[clear, :k]) and np.array_equal(i_bf[clear], i_ref[clear, :k])
+        assert np.allclose(d_kd[clear], d_ref[clear, :k] ** 2, rtol=2e-6, atol=1e-9)
+
+
+def test_pose_logmap_against_the_matrix_logarithm():
+    """gtsam::Pose3::Logmap (restated in the oracle for the transform gate,
+    IcpLoopComputation.cc:604-614) against scipy's general matrix logarithm of the 4 x 4 matrix."""
+    linalg = pytest.importorskip("scipy.linalg")
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        w = rng.normal(0, 0.6, 3)
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+        t = rng.normal(0, 2.0, 3)
+        # quaternion of R (w, x, y, z)
+        qw = 0.5 * np.sqrt(1 + np.trace(R))
+        q = np.array([qw, (R[2, 1] - R[1, 2]) / (4 * qw), (R[0, 2] - R[2, 0]) / (4 * qw), (R[1, 0] - R[0, 1]) / (4 * qw)])
+        xi = O.pose_logmap(O.pose_from_quat(q, t))
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        Lg = np.real(linalg.logm(T))
+        assert np.allclose(xi[:3], [Lg[2, 1], Lg[0, 2], Lg[1, 0]], atol=1e-9)
+        assert np.allclose(xi[3:], Lg[:3, 3], atol=1e-9)
+
+
+def test_knn_normals_against_numpy_eigenvectors():
+    """lamp_utils::ComputeNormals (pcl::NormalEstimation over the 10 nearest neighbours): the normal
+    is the eigenvector of the neighbourhood covariance with the smallest eigenvalue, up to its
+    sign.  LAPACK's symmetric eigensolver on the same neighbourhoods."""
+    xyz, _ = F.random_room_scan(3000, 41)
+    nrm, _ = O.compute_normals(xyz, 10)
+    idx, _ = O.knn_brute(xyz, xyz, 10)
+    P = xyz.astype(np.float64)[idx]
+    c = P - P.mean(axis=1, keepdims=True)
+    ev, V = np.linalg.eigh(np.einsum("nki,nkj->nij", c, c))
+    want = V[:, :, 0]
+    well = (ev[:, 1] - ev[:, 0]) / np.maximum(ev[:, 2], 1e-30) > 1e-3
+    cos = np.abs(np.einsum("ni,ni->n", nrm.astype(np.float64), want))
+    assert well.mean() > 0.9
+    assert cos[well].min() > 1 - 1e-4, cos[well].min()
