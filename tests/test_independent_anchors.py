@@ -231,3 +231,23 @@ def test_fpfh_against_a_numpy_restatement():
     assert np.allclose(want.reshape(7, 3, 11).sum(-1), 100, atol=1e-9)
     err = np.abs(got - want)
     assert np.median(err) < 1e-6 and err.max() < 1e-3, (np.median(err), err.max())
+
+
+def test_harris_response_against_numpy():
+    """pcl::HarrisKeypoint3D's HARRIS response on given normals (PointCloudUtils.cc:78-96): mean of
+    n n^T over the neighbours within the radius, r = 0.04 + det - 0.04 trace^2 in float.  The same
+    in numpy double."""
+    xyz, nrm = F.random_room_scan(1200, 13, noise=0.02)
+    got = O.harris_response(xyz, nrm, 0.6)
+    p, n = xyz.astype(np.float64), nrm.astype(np.float64)
+    d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+    inside = d2 < 0.36
+    want = np.zeros(len(p))
+    for i in range(len(p)):
+        nb = n[inside[i]]
+        C = nb.T @ nb / len(nb)
+        tr = np.trace(C)
+        want[i] = 0.04 + np.linalg.det(C) - 0.04 * tr * tr if tr != 0 else 0.0
+    # (det and 0.04 trace^2 cancel to ~1e-3 of their size: float sums leave ~1e-6 absolute)
+    assert np.allclose(got, want, atol=5e-6), np.abs(got - want).max()
+    assert np.abs(want).max() > 1e-3
