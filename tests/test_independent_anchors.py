@@ -251,3 +251,99 @@ def test_harris_response_against_numpy():
     # (det and 0.04 trace^2 cancel to ~1e-3 of their size: float sums leave ~1e-6 absolute)
     assert np.allclose(got, want, atol=5e-6), np.abs(got - want).max()
     assert np.abs(want).max() > 1e-3
+
+
+def test_teaser_scalar_tls_against_exhaustive_search():
+    """The scalar TLS estimator of TEASER++ (adaptive voting: one sweep over the 2n interval ends
+    with running sums) against a direct evaluation of what the sweep enumerates: for a point in
+    every gap between two interval ends, the measurements whose interval [a_i - c, a_i + c] holds
+    it, their mean, and the library's cost for that consensus set -- squared residuals of the
+    members plus c (the library adds the ranges, not their squares) per measurement left out."""
+    rng = np.random.default_rng(17)
+    for trial in range(40):
+        n = int(rng.integers(5, 40))
+        a = np.concatenate([rng.normal(2.0, 0.15, n), rng.uniform(-8, 8, int(rng.integers(0, n)))])
+        c = float(rng.uniform(0.2, 0.8))
+        got = O.teaser_tls_scalar(a, c)
+        ends = np.sort(np.concatenate([a - c, a + c]))
+        best, best_x = np.inf, None
+        for p in 0.5 * (ends[:-1] + ends[1:]):
+            member = np.abs(a - p) <= c
+            if not member.any():
+                continue
+            x = a[member].mean()
+            cost = ((x - a[member]) ** 2).sum() + c * (~member).sum()
+            if cost < best:
+                best, best_x = cost, x
+        assert abs(got - best_x) < 1e-9, (trial, got, best_x)
+
+
+def test_teaser_gnc_rotation_is_the_least_squares_rotation_of_its_inliers():
+    """GNC-TLS ends with weights 0 or 1: with no measurement beyond the noise bound the rotation it
+    returns is the plain least-squares rotation of all of them (Kabsch / Horn through LAPACK's
+    SVD); with gross outliers added, that of the inliers alone."""
+    from scipy.spatial.transform import Rotation as Rsc
+    rng = np.random.default_rng(23)
+
+    def kabsch(x, y):
+        U, _, Vt = np.linalg.svd(y.T @ x)
+        D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))])
+        return U @ D @ Vt
+
+    R = Rsc.from_rotvec([0.4, -0.9, 0.3]).as_matrix()
+    x = rng.normal(0, 3.0, (80, 3))
+    y = x @ R.T + rng.normal(0, 0.02, x.shape)
+    got = O.teaser_gnc_rotation(x, y, noise_bound=0.5)
+    assert np.abs(got - kabsch(x, y)).max() < 1e-6
+    y_out = y.copy()
+    y_out[:25] = rng.normal(0, 6.0, (25, 3))                 # a third of the measurements are junk
+    got = O.teaser_gnc_rotation(x, y_out, noise_bound=0.5)
+    # (an outlier may land within the bound of its prediction by chance: compare on those that do not)
+    far = np.linalg.norm(y_out[:25] - x[:25] @ R.T, axis=1) > 1.0
+    keep = np.r_[np.flatnonzero(~far), np.arange(25, 80)]
+    assert np.abs(got - kabsch(x[keep], y_out[keep])).max() < 1e-6
+
+
+def test_teaser_clique_against_exact_search():
+    """The greedy clique heuristic (what TEASER++ runs by default through PMC) on random graphs with
+    a planted clique, against an exact maximum-clique search (Bron-Kerbosch with pivoting, written
+    here): what it returns is a clique, and on these graphs -- sparse noise around one dense
+    consistent set, the shape of a TEASER++ consistency graph -- it is a maximum one."""
+    rng = np.random.default_rng(29)
+
+    def max_clique(adj):
+        n = len(adj)
+        nbrs = [set(np.flatnonzero(adj[i])) for i in range(n)]
+        best = []
+
+        def expand(R, P, X):
+            nonlocal best
+            if not P and not X:
+                if len(R) > len(best):
+                    best = list(R)
+                return
+            if len(R) + len(P) <= len(best):
+                return
+            pivot = max(P | X, key=lambda u: len(P & nbrs[u]))
+            for v in list(P - nbrs[pivot]):
+                expand(R + [v], P & nbrs[v], X & nbrs[v])
+                P = P - {v}
+                X = X | {v}
+
+        expand([], set(range(n)), set())
+        return best
+
+    exact_hits = 0
+    for trial in range(12):
+        n, k = 60, 14
+        adj = (rng.random((n, n)) < 0.15).astype(np.uint8)
+        adj = np.triu(adj, 1)
+        adj = adj + adj.T
+        planted = rng.choice(n, k, replace=False)
+        adj[np.ix_(planted, planted)] = 1
+        np.fill_diagonal(adj, 0)
+        got = list(O.teaser_clique(adj))
+        assert all(adj[a, b] for i, a in enumerate(got) for b in got[i + 1:])     # a clique
+        assert len(got) >= k
+        exact_hits += len(got) == len(max_clique(adj))
+    assert exact_hits == 12
