@@ -366,6 +366,29 @@ def test_device_lands_where_an_independent_minimiser_lands(n, seed, rot_deg, tra
     assert np.max(np.abs(T_np.astype(np.float64) - np.asarray(got["T"], np.float64))) < 2e-7
 
 
+@pytest.mark.parametrize("config", ["C2", "C3"])
+def test_device_lands_where_an_independent_minimiser_lands_at_benchmark_size(config):
+    """The same at the size of the benchmark configurations (16,384- and 32,768-point VLP-16-like
+    keyframes, base-station parameters, identity guess) through lgicp_submit."""
+    from lamp_amd import capi
+    from lamp_amd.workload import Workload
+    from tests.test_independent_anchors import _gicp_numpy
+    work = Workload(config, pairs=1, keyframes=2)
+    (a, b), = work.pairs
+    src, sn = work.keyframes[a]
+    tgt, tn = work.keyframes[b]
+    T_np = _gicp_numpy(src, sn, tgt, tn, iterations=60)
+    c = capi.Context(init_method=capi.INIT_IDENTITY, transform_thresholding=0)
+    try:
+        work.register(c)
+        d = capi.result_to_dict(c.submit(work.candidates())[0])
+    finally:
+        c.close()
+    assert d["status"] == 0
+    ang, te = O.pose_gap(T_np, d["T_icp"])
+    assert ang < 1e-7 and te < 1e-7, (config, ang, te)
+
+
 def test_reference_known_answer_with_the_reference_solver():
     """TestLoopComputation.PerformAlignment (loop_closure/test/test_loop_computation.cc:125-182):
     corner against the corner shifted by (1, -0.001, 0), the test's perturbed odometry poses, the base
