@@ -347,3 +347,34 @@ def test_teaser_clique_against_exact_search():
         assert len(got) >= k
         exact_hits += len(got) == len(max_clique(adj))
     assert exact_hits == 12
+
+
+def test_fitness_score_against_scipy():
+    """pcl getFitnessScore (mean squared distance of the aligned source to its nearest target,
+    IcpLoopComputation.cc:586) with scipy's cKDTree and double arithmetic."""
+    spatial = pytest.importorskip("scipy.spatial")
+    src, _, tgt, _, T = F.make_pair(3000, 51, rot_deg=3.0, trans=0.3)
+    T = np.asarray(T, np.float32)
+    got, idx = O.fitness_score(src, tgt, T)
+    moved = src.astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3].astype(np.float64)
+    d, i = spatial.cKDTree(tgt.astype(np.float64)).query(moved)
+    assert abs(got - np.mean(d ** 2)) <= 2e-6 * np.mean(d ** 2)
+    assert (idx == i).mean() > 0.999
+
+
+def test_voxel_grid_against_numpy():
+    """pcl::VoxelGrid with a cubic leaf (LampPcldFilter.cc:12-72): one centroid per occupied voxel,
+    voxels counted from floor(min / leaf).  The same grouping with numpy; PCL's order of the output
+    (by voxel index) is not part of the comparison."""
+    xyz, _ = F.random_room_scan(5000, 61, noise=0.01)
+    leaf = 0.25
+    got = O.voxel_grid(xyz, leaf)
+    cell = np.floor(xyz.astype(np.float64) / leaf).astype(np.int64)
+    _, inv, cnt = np.unique(cell, axis=0, return_inverse=True, return_counts=True)
+    want = np.zeros((len(cnt), 3))
+    np.add.at(want, inv.ravel(), xyz.astype(np.float64))
+    want /= cnt[:, None]
+    assert len(got) == len(want)
+    order_g = np.lexsort(np.floor(got.astype(np.float64) / leaf).T)
+    order_w = np.lexsort(np.floor(want / leaf).T)
+    assert np.allclose(got[order_g], want[order_w], atol=2e-5)
