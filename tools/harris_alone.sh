@@ -1,3 +1,6 @@
+# Durations of the feature front end's kernels (Harris, FPFH) when one keyframe is processed alone:
+# rocprofv3 --kernel-trace --stats around tools/harris_alone_probe.py.
+# usage (GPU box, repository root): bash tools/harris_alone.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/ha
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ha -o k -- python3 tools/harris_alone_probe.py > gpurun_out/ha.log 2>&1 || exit 1
